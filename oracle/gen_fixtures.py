@@ -1,0 +1,125 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/: small JPEGs plus the reference's own outputs for them.
+
+TEST INFRASTRUCTURE.  Run in the build container only (needs Pillow to encode and
+oracle/_ref/libjpegref.so, i.e. the compiled, unmodified reference, to decode):
+
+    make -C oracle && python oracle/gen_fixtures.py
+
+Each fixture is data: ``<name>.jpg`` (the input) and ``<name>.npz`` holding what the
+reference produced for it -- ``coefs`` (Huffman-decoded blocks, zigzag order, scan
+order, DC prediction applied), ``plane0..2`` (padded component planes) and ``rgb``.
+``manifest.json`` lists them with the encoder settings and SHA-256 digests.
+"""
+import hashlib
+import io
+import json
+import os
+import sys
+
+import numpy as np
+from PIL import Image
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from refbind import Ref  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+
+def synth(W, H, seed, sigma=12.0):
+    """Gradient + Gaussian noise, the benchmark's synthetic image recipe."""
+    rng = np.random.default_rng(seed)
+    x = np.arange(W, dtype=np.float64)[None, :]
+    y = np.arange(H, dtype=np.float64)[:, None]
+    base = np.stack([255 * x / max(W - 1, 1) + 0 * y, 255 * y / max(H - 1, 1) + 0 * x,
+                     255 * (x + y) / max(W + H - 2, 1)], -1)
+    return np.clip(base + rng.normal(0, sigma, (H, W, 3)), 0, 255).astype(np.uint8)
+
+
+def edges(W, H, seed):
+    """Saturated checker + bars: drives the IDCT clamp and the colour clamp."""
+    rng = np.random.default_rng(seed)
+    x = np.arange(W)[None, :]
+    y = np.arange(H)[:, None]
+    chk = (((x // 5) + (y // 3)) % 2) * 255
+    img = np.stack([chk, 255 - chk, ((x // 7) % 2) * 255 + 0 * y], -1).astype(np.float64)
+    img += rng.normal(0, 3, img.shape)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def flat(W, H, rgb):
+    return np.broadcast_to(np.array(rgb, np.uint8), (H, W, 3)).copy()
+
+
+# name, image factory, mode, save kwargs
+FIXTURES = [
+    ("c420_q85_64x48", lambda: synth(64, 48, 1), "RGB", dict(quality=85, subsampling="4:2:0")),
+    ("c420_q85_100x75_ri3", lambda: synth(100, 75, 2), "RGB", dict(quality=85, subsampling="4:2:0", restart_marker_blocks=3)),
+    ("c420_q50_opt_96x80", lambda: synth(96, 80, 3), "RGB", dict(quality=50, subsampling="4:2:0", optimize=True)),
+    ("c420_q95_160x120_rirow", lambda: synth(160, 120, 4), "RGB", dict(quality=95, subsampling="4:2:0", restart_marker_rows=1)),
+    ("c420_q90_ri1_48x32", lambda: synth(48, 32, 5), "RGB", dict(quality=90, subsampling="4:2:0", restart_marker_blocks=1)),
+    ("c420_q85_flat_64x64", lambda: flat(64, 64, (200, 30, 90)), "RGB", dict(quality=85, subsampling="4:2:0")),
+    ("c420_q90_edges_112x64", lambda: edges(112, 64, 6), "RGB", dict(quality=90, subsampling="4:2:0")),
+    ("c420_q100_edges_40x40", lambda: edges(40, 40, 7), "RGB", dict(quality=100, subsampling="4:2:0", restart_marker_rows=1)),
+    ("c422_q75_120x72", lambda: synth(120, 72, 8), "RGB", dict(quality=75, subsampling="4:2:2")),
+    ("c422_q95_opt_136x40_ri5", lambda: synth(136, 40, 9), "RGB", dict(quality=95, subsampling="4:2:2", optimize=True, restart_marker_blocks=5)),
+    ("c422_q50_33x17", lambda: synth(33, 17, 10), "RGB", dict(quality=50, subsampling="4:2:2")),
+    ("c444_q85_80x56_rirow", lambda: synth(80, 56, 11), "RGB", dict(quality=85, subsampling="4:4:4", restart_marker_rows=1)),
+    ("c444_q75_opt_57x43", lambda: synth(57, 43, 12), "RGB", dict(quality=75, subsampling="4:4:4", optimize=True)),
+    ("c444_q95_qtab_72x48", lambda: synth(72, 48, 13), "RGB",
+     dict(subsampling="4:4:4", qtables=[[max(1, (3 * i) % 97 + 1) for i in range(64)], [max(1, (7 * i) % 61 + 2) for i in range(64)]])),
+    ("c444_q30_edges_64x64", lambda: edges(64, 64, 14), "RGB", dict(quality=30, subsampling="4:4:4")),
+    ("g_q50_64x64", lambda: synth(64, 64, 15)[..., 0], "L", dict(quality=50)),
+    ("g_q95_opt_120x88_rirow", lambda: synth(120, 88, 16)[..., 1], "L", dict(quality=95, optimize=True, restart_marker_rows=1)),
+    ("g_q75_72x40_ri4", lambda: synth(72, 40, 17)[..., 2], "L", dict(quality=75, restart_marker_blocks=4)),
+    ("g_q85_edges_48x48", lambda: edges(48, 48, 18)[..., 0], "L", dict(quality=85)),
+    # BASELINE config 1: the reference's own CPU-runnable case
+    ("C1_c420_q85_512x512", lambda: synth(512, 512, 0), "RGB", dict(quality=85, subsampling="4:2:0")),
+]
+
+# Known divergences: the reference drops a final MCU that starts inside the last
+# entropy-coded byte (decode.c:578-589 / bitstream.c:118-131); only tiny grey MCUs
+# can be that short.  Kept as a documented case, not a parity case.
+DIVERGENT = [
+    ("g_flat_32x8_refdrops", lambda: np.full((8, 32), 128, np.uint8), "L", dict(quality=85)),
+]
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ref = Ref()
+    manifest = {"generator": "oracle/gen_fixtures.py", "pillow": Image.__version__, "fixtures": []}
+    for group, divergent in ((FIXTURES, False), (DIVERGENT, True)):
+        for name, make, mode, kw in group:
+            arr = make()
+            buf = io.BytesIO()
+            Image.fromarray(arr, mode).save(buf, "JPEG", **kw)
+            data = buf.getvalue()
+            d = ref.decode(data)
+            with open(os.path.join(OUT, name + ".jpg"), "wb") as f:
+                f.write(data)
+            arrays = {"coefs": d.coefs, "rgb": d.rgb}
+            for i, p in enumerate(d.planes):
+                arrays[f"plane{i}"] = p
+            np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrays)
+            kwj = {k: v for k, v in kw.items() if k != "qtables"}
+            if "qtables" in kw:
+                kwj["qtables"] = "custom"
+            manifest["fixtures"].append({
+                "name": name, "mode": mode, "X": d.X, "Y": d.Y, "ncs": d.ncs,
+                "hsf": d.hsf, "vsf": d.vsf, "encoder": kwj, "jpeg_bytes": len(data),
+                "ref_blocks": int(d.coefs.shape[0]), "divergent": divergent,
+                "sha256_coefs": sha(d.coefs), "sha256_rgb": sha(d.rgb),
+            })
+            print(f"{name:32s} {len(data):7d} B  blocks={d.coefs.shape[0]}")
+    with open(os.path.join(OUT, "manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
