@@ -1,0 +1,7 @@
+/* Drop-in name for the reference's src/frame_header.h: the declarations live in
+ * mi355jpeg_compat.h so that a translation unit written against the reference's
+ * headers (e.g. its jpeg_decoder.c) compiles unchanged against this library. */
+#ifndef MI355JPEG_FWD_FRAME_HEADER_H
+#define MI355JPEG_FWD_FRAME_HEADER_H
+#include "mi355jpeg_compat.h"
+#endif

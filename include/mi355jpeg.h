@@ -1,0 +1,132 @@
+/*
+ * mi355jpeg.h -- C ABI of libmi355jpeg.so, the MI355X (gfx950) baseline-JPEG
+ * decode path.  Plain pointers and sizes only; callable from C, ctypes, cgo, JNI.
+ *
+ * The reference decoder has no library or FFI boundary of its own: it is one
+ * executable whose main() calls decode_jpeg_buffer() and ycbcr_rgb()
+ * (jpeg_decoder.c:55, :95-98).  Those names are exported too (see
+ * mi355jpeg_compat.h).  The functions below are the part the single-image API
+ * cannot express: a device context and a batch of images that is decoded by one
+ * sequence of kernel launches with every input and output resident in HBM.
+ *
+ * Hot path replaced, per stage (reference file:line -> kernel):
+ *   bitstream.c:22-176 (FF00 unstuffing, RSTn discovery)      -> mj_k_scan_*
+ *   decode.c:535-723   (decode_scan / decode_data_unit)       -> mj_k_entropy_*
+ *   quant_table.c:131-152 + dct.c:158-204,296-341 + decode.c:436-533
+ *   + colour_conversion.c:5-83 (dequant, IDCT, planes, RGB)   -> mj_k_idct_colour
+ *
+ * All functions return 0 on success and a negative value on failure;
+ * mj_last_error() returns a thread-local message for the last failure.
+ */
+#ifndef MI355JPEG_H
+#define MI355JPEG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "mi355jpeg_compat.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mj_ctx mj_ctx;
+typedef struct mj_batch mj_batch;
+
+/* flags for mj_batch_create */
+#define MJ_WANT_PLANES 0x1u   /* also store the padded u8 component planes (Image.buf) */
+#define MJ_TIMING      0x2u   /* bracket every kernel with HIP events on the batch stream */
+#define MJ_ENTROPY_SERIAL 0x4u /* diagnostic: one lane per restart interval, no subsequence sync */
+
+typedef struct {
+    int32_t X, Y;            /* frame size in pixels */
+    int32_t ncs;             /* 1 (grey) or 3 (YCbCr) */
+    int32_t hsf[4], vsf[4];  /* sampling factors per component */
+    int32_t plane_w[4], plane_h[4]; /* padded plane sizes (decode.c:108-115) */
+    int32_t mcus_x, mcus_y;  /* MCU grid */
+    int32_t blocks_per_mcu;
+    int32_t restart_interval; /* MCUs per interval, 0 = none */
+    int32_t n_intervals;
+    int64_t n_blocks;        /* 8x8 blocks in the scan */
+    int64_t entropy_bytes;   /* bytes handed to the GPU (from SOS data to end of file) */
+    int64_t rgb_pitch;       /* bytes per RGB row in the device buffer */
+    int64_t coef_offset;     /* first block of this image in the batch coefficient buffer */
+    int64_t rgb_offset;      /* first byte of this image in the batch RGB buffer */
+} mj_image_info;
+
+/* kernel slots reported by mj_batch_kernel_ms (MJ_TIMING) */
+enum {
+    MJ_T_SCAN = 0,     /* unstuff + restart-marker discovery + subsequence layout */
+    MJ_T_ENTROPY = 1,  /* Huffman decode (sync + write) */
+    MJ_T_ENTROPY_FIX = 2, /* cross-sequence fix-up and second write pass (no-RST scans) */
+    MJ_T_IDCT_COLOUR = 3, /* dequant + IDCT + upsample + YCbCr->RGB */
+    MJ_T_MEMSET = 4,   /* zero-fill of the coefficient buffer */
+    MJ_T_COUNT = 5
+};
+
+const char *mj_last_error(void);
+
+/* Device context: owns a HIP stream on `device`.  Fails (no CPU fallback) when
+ * no HIP device is usable. */
+int mj_create(int device, mj_ctx **out);
+void mj_destroy(mj_ctx *ctx);
+/* Use the caller's hipStream_t (e.g. the framework's current stream) instead of
+ * the context's own.  Pass NULL to go back to the context's stream. */
+int mj_set_stream(mj_ctx *ctx, void *hip_stream);
+
+/* Parse n baseline JPEG files with the host parsers (decode_frame_header,
+ * decode_huff_tables, decode_quant_table, decode_restart_interval,
+ * decode_scan_header -- the reference's decode.c:160-415 marker walk), flatten
+ * their tables, allocate device buffers and copy the entropy-coded bytes to HBM.
+ * bufs[i] is borrowed for the duration of the call only. */
+int mj_batch_create(mj_ctx *ctx, const uint8_t *const *bufs, const size_t *lens, int n, uint32_t flags,
+                    mj_batch **out);
+/* A batch of one image from already-parsed structs: what the reference hands to
+ * decode_scan() at its SOS case (decode.c:333; prototype decode.c:37-45).
+ * `entropy` points at the first entropy-coded byte; entropy_len may run to the end
+ * of the file -- the scan kernels find the marker that ends the segment. */
+int mj_batch_create_scan(mj_ctx *ctx, const uint8_t *entropy, size_t entropy_len, const FrameHeader *fh,
+                         const ScanHeader *sh, const HuffTables *hts, const QuantTables *qts, RestartInterval ri,
+                         uint32_t flags, mj_batch **out);
+void mj_batch_destroy(mj_batch *b);
+
+/* Enqueue the whole hot path for the batch on the stream (asynchronous).  Inputs
+ * are already resident in HBM; outputs (coefficients, RGB, optional planes) stay
+ * in HBM.  May be called repeatedly; every call decodes from scratch. */
+int mj_batch_decode(mj_batch *b);
+int mj_batch_sync(mj_batch *b);
+
+int mj_batch_size(const mj_batch *b);
+int mj_batch_image_info(const mj_batch *b, int i, mj_image_info *info);
+/* Per-image status word written by the kernels: 0 = ok, bit 0 = entropy data
+ * ended early or overran, bit 1 = fewer restart markers than the header implies. */
+int mj_batch_status(mj_batch *b, int i, uint32_t *status);
+
+/* Offset, from the first entropy-coded byte of image i, of the marker that ends its
+ * segment (EOI or the next table/scan segment); the segment length if none was
+ * found.  This is where the reference's cursor stands when decode_scan returns. */
+int mj_batch_scan_end(mj_batch *b, int i, size_t *offset);
+
+/* Device pointers (valid until mj_batch_destroy). */
+void *mj_batch_device_rgb(const mj_batch *b);    /* uint8, image i at rgb_offset, rows of rgb_pitch */
+void *mj_batch_device_coefs(const mj_batch *b);  /* int16[64] per block, zigzag order, scan order */
+
+/* Synchronous device-to-host copies for checking results. */
+int mj_batch_copy_rgb(mj_batch *b, int i, uint8_t *dst, size_t dst_pitch);
+int mj_batch_copy_coefs(mj_batch *b, int i, int16_t *dst);          /* n_blocks*64 */
+int mj_batch_copy_plane(mj_batch *b, int i, int comp, uint8_t *dst); /* plane_w*plane_h, needs MJ_WANT_PLANES */
+
+/* Accumulated kernel time since the last mj_batch_reset_timing, from HIP events
+ * recorded on the stream the kernels run on.  Also returns the launch count. */
+int mj_batch_kernel_ms(mj_batch *b, float ms[MJ_T_COUNT], int launches[MJ_T_COUNT]);
+int mj_batch_reset_timing(mj_batch *b);
+
+/* Entropy-stage statistics of the last decode (device counters, read back):
+ * [0] subsequences, [1] sync rounds summed over sequences, [2] max rounds in a
+ * sequence, [3] sequences, [4] multi-sequence intervals, [5] fix-up iterations. */
+int mj_batch_entropy_stats(mj_batch *b, int64_t stats[8]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355JPEG_H */

@@ -1,0 +1,223 @@
+"""ctypes binding of the C ABI in include/mi355jpeg.h (libmi355jpeg.so).
+
+No torch types cross this boundary and there is no CPU decode fallback: if the
+library or a HIP device is missing, construction raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmi355jpeg.so")
+EMU_PATH = os.path.join(_HERE, "libmjemu.so")
+
+MJ_WANT_PLANES = 0x1
+MJ_TIMING = 0x2
+MJ_ENTROPY_SERIAL = 0x4
+T_SCAN, T_ENTROPY, T_ENTROPY_FIX, T_IDCT_COLOUR, T_MEMSET, T_COUNT = 0, 1, 2, 3, 4, 5
+KERNEL_NAMES = ["scan", "entropy", "entropy_fix", "idct_colour", "memset"]
+
+# every symbol include/mi355jpeg.h and include/mi355jpeg_compat.h declare
+ABI_SYMBOLS = [
+    "mj_last_error", "mj_create", "mj_destroy", "mj_set_stream", "mj_batch_create", "mj_batch_destroy", "mj_batch_create_scan", "mj_batch_scan_end",
+    "mj_batch_decode", "mj_batch_sync", "mj_batch_size", "mj_batch_image_info", "mj_batch_status",
+    "mj_batch_device_rgb", "mj_batch_device_coefs", "mj_batch_copy_rgb", "mj_batch_copy_coefs",
+    "mj_batch_copy_plane", "mj_batch_kernel_ms", "mj_batch_reset_timing", "mj_batch_entropy_stats",
+]
+COMPAT_SYMBOLS = [
+    "get_byte", "next_byte", "next_bit", "next_bit_size", "check_marker", "next_byte_restart_marker", "progress",
+    "encoding_str", "decode_frame_header", "decode_number_of_lines", "free_frame_header", "print_frame_header",
+    "print_component", "decode_scan_header", "print_scan_header", "print_image_component", "new_huff_tables",
+    "decode_huff_tables", "free_huff_tables", "print_huff_tables", "print_huff_table", "zigzag",
+    "decode_quant_table", "dequant_data_unit", "decode_restart_interval", "allocate_img", "free_img",
+    "decode_jpeg_buffer", "decode_scan", "y_rgb", "ycbcr_rgb", "get_max_sf",
+]
+
+
+class ImageInfo(C.Structure):
+    _fields_ = [
+        ("X", C.c_int32), ("Y", C.c_int32), ("ncs", C.c_int32),
+        ("hsf", C.c_int32 * 4), ("vsf", C.c_int32 * 4),
+        ("plane_w", C.c_int32 * 4), ("plane_h", C.c_int32 * 4),
+        ("mcus_x", C.c_int32), ("mcus_y", C.c_int32), ("blocks_per_mcu", C.c_int32),
+        ("restart_interval", C.c_int32), ("n_intervals", C.c_int32),
+        ("n_blocks", C.c_int64), ("entropy_bytes", C.c_int64), ("rgb_pitch", C.c_int64),
+        ("coef_offset", C.c_int64), ("rgb_offset", C.c_int64),
+    ]
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen libmi355jpeg.so and declare its prototypes.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: build it with __graft_entry__.build() "
+                           "(make -C jpeg-decoder_amd); there is no fallback path")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, u32 = C.c_void_p, C.c_int, C.c_uint32
+    lib.mj_last_error.restype = C.c_char_p
+    lib.mj_create.argtypes = [i32, C.POINTER(vp)]
+    lib.mj_destroy.argtypes = [vp]
+    lib.mj_destroy.restype = None
+    lib.mj_set_stream.argtypes = [vp, vp]
+    lib.mj_batch_create.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), i32, u32, C.POINTER(vp)]
+    lib.mj_batch_destroy.argtypes = [vp]
+    lib.mj_batch_destroy.restype = None
+    lib.mj_batch_decode.argtypes = [vp]
+    lib.mj_batch_sync.argtypes = [vp]
+    lib.mj_batch_size.argtypes = [vp]
+    lib.mj_batch_image_info.argtypes = [vp, i32, C.POINTER(ImageInfo)]
+    lib.mj_batch_status.argtypes = [vp, i32, C.POINTER(u32)]
+    lib.mj_batch_device_rgb.argtypes = [vp]
+    lib.mj_batch_device_rgb.restype = vp
+    lib.mj_batch_device_coefs.argtypes = [vp]
+    lib.mj_batch_device_coefs.restype = vp
+    lib.mj_batch_copy_rgb.argtypes = [vp, i32, vp, C.c_size_t]
+    lib.mj_batch_copy_coefs.argtypes = [vp, i32, vp]
+    lib.mj_batch_copy_plane.argtypes = [vp, i32, i32, vp]
+    lib.mj_batch_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    lib.mj_batch_reset_timing.argtypes = [vp]
+    lib.mj_batch_entropy_stats.argtypes = [vp, C.POINTER(C.c_int64)]
+    _lib = lib
+    return lib
+
+
+def _check(lib, rc, what):
+    if rc != 0:
+        msg = lib.mj_last_error()
+        raise RuntimeError(f"{what} failed ({rc}): {msg.decode() if msg else '?'}")
+
+
+class Context:
+    """mj_ctx: one per GPU / host thread."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        self.h = C.c_void_p()
+        _check(self.lib, self.lib.mj_create(device, C.byref(self.h)), "mj_create")
+
+    def set_stream(self, hip_stream_ptr):
+        _check(self.lib, self.lib.mj_set_stream(self.h, C.c_void_p(hip_stream_ptr)), "mj_set_stream")
+
+    def batch(self, files, flags=0):
+        return Batch(self, files, flags)
+
+    def close(self):
+        if self.h:
+            self.lib.mj_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Batch:
+    """mj_batch: n JPEG files parsed, laid out and resident in HBM."""
+
+    def __init__(self, ctx, files, flags=0):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        n = len(files)
+        bufs = (C.c_char_p * n)(*files)
+        lens = (C.c_size_t * n)(*[len(f) for f in files])
+        self.h = C.c_void_p()
+        _check(self.lib, self.lib.mj_batch_create(ctx.h, bufs, lens, n, flags, C.byref(self.h)), "mj_batch_create")
+        self.n = n
+        self.flags = flags
+
+    def decode(self):
+        _check(self.lib, self.lib.mj_batch_decode(self.h), "mj_batch_decode")
+
+    def sync(self):
+        _check(self.lib, self.lib.mj_batch_sync(self.h), "mj_batch_sync")
+
+    def info(self, i):
+        inf = ImageInfo()
+        _check(self.lib, self.lib.mj_batch_image_info(self.h, i, C.byref(inf)), "mj_batch_image_info")
+        return inf
+
+    def status(self, i):
+        s = C.c_uint32()
+        _check(self.lib, self.lib.mj_batch_status(self.h, i, C.byref(s)), "mj_batch_status")
+        return s.value
+
+    def rgb(self, i):
+        inf = self.info(i)
+        out = np.empty((inf.Y, inf.X, 3), np.uint8)
+        _check(self.lib, self.lib.mj_batch_copy_rgb(self.h, i, out.ctypes.data, 3 * inf.X), "mj_batch_copy_rgb")
+        return out
+
+    def coefs(self, i):
+        inf = self.info(i)
+        out = np.empty((inf.n_blocks, 64), np.int16)
+        _check(self.lib, self.lib.mj_batch_copy_coefs(self.h, i, out.ctypes.data), "mj_batch_copy_coefs")
+        return out
+
+    def plane(self, i, comp):
+        inf = self.info(i)
+        out = np.empty((inf.plane_h[comp], inf.plane_w[comp]), np.uint8)
+        _check(self.lib, self.lib.mj_batch_copy_plane(self.h, i, comp, out.ctypes.data), "mj_batch_copy_plane")
+        return out
+
+    def device_rgb_ptr(self):
+        return self.lib.mj_batch_device_rgb(self.h)
+
+    def device_coefs_ptr(self):
+        return self.lib.mj_batch_device_coefs(self.h)
+
+    def kernel_ms(self):
+        ms = (C.c_float * T_COUNT)()
+        cnt = (C.c_int * T_COUNT)()
+        _check(self.lib, self.lib.mj_batch_kernel_ms(self.h, ms, cnt), "mj_batch_kernel_ms")
+        return {KERNEL_NAMES[i]: (float(ms[i]), int(cnt[i])) for i in range(T_COUNT)}
+
+    def reset_timing(self):
+        _check(self.lib, self.lib.mj_batch_reset_timing(self.h), "mj_batch_reset_timing")
+
+    def entropy_stats(self):
+        st = (C.c_int64 * 8)()
+        _check(self.lib, self.lib.mj_batch_entropy_stats(self.h, st), "mj_batch_entropy_stats")
+        keys = ["subsequences", "rounds_sum", "rounds_max", "sequences", "multi_seq_intervals", "fix_iterations",
+                "r6", "r7"]
+        return dict(zip(keys, [int(v) for v in st]))
+
+    def close(self):
+        if self.h:
+            self.lib.mj_batch_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Emu:
+    """Host emulation of the entropy kernels' algorithm (libmjemu.so); CPU tests only."""
+
+    def __init__(self):
+        if not os.path.exists(EMU_PATH):
+            raise RuntimeError(f"{EMU_PATH} missing: run __graft_entry__.build()")
+        self.lib = C.CDLL(EMU_PATH)
+        self.lib.mj_emu_decode_coefs.restype = C.c_int64
+        self.lib.mj_emu_decode_coefs.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_int64, C.c_uint32,
+                                                 C.POINTER(C.c_int64)]
+
+    def decode_coefs(self, data, n_blocks_cap, sub_bits=0):
+        out = np.zeros((n_blocks_cap, 64), np.int16)
+        st = (C.c_int64 * 8)()
+        n = self.lib.mj_emu_decode_coefs(data, len(data), out.ctypes.data, n_blocks_cap, sub_bits, st)
+        if n < 0:
+            raise RuntimeError("mj_emu_decode_coefs failed")
+        keys = ["subsequences", "rounds_sum", "rounds_max", "sequences", "multi_seq_intervals", "fix_iterations",
+                "sub_bits", "n_rst"]
+        return out[:n], dict(zip(keys, [int(v) for v in st]))

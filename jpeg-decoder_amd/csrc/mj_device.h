@@ -1,0 +1,109 @@
+/*
+ * mj_device.h -- descriptors shared by the host side (C, flatten.c) and the HIP
+ * kernels.  Plain C structs with fixed-width members; the host fills them, they are
+ * copied to HBM once per batch, and every kernel indexes them by image.
+ */
+#ifndef MJ_DEVICE_H
+#define MJ_DEVICE_H
+
+#include <stdint.h>
+
+#define MJ_MAX_COMP 4
+#define MJ_MAX_BPM 10          /* T.81 B.2.3: at most 10 blocks per MCU */
+#define MJ_MAX_TABS 8          /* Huffman tables one scan can reference */
+#define MJ_LUT_BITS 10
+#define MJ_LUT_SIZE (1 << MJ_LUT_BITS)
+#define MJ_SEQ_SUBS 64         /* subsequences per sequence = lanes per wavefront */
+#define MJ_SCAN_TILE 4096      /* raw bytes per scan-kernel workgroup */
+#define MJ_STREAM_PAD 64       /* readable zero bytes after every compacted stream */
+#define MJ_NO_TERMINATOR 0xFFFFFFFFu
+
+/* One Huffman table, flattened from the reference's HuffTable (huff_table.h:9-14):
+ * a direct lookup on the next MJ_LUT_BITS bits for short codes, and the canonical
+ * ranges (decode.c:674-681 compares against max_codes per length) for longer ones. */
+typedef struct {
+    uint16_t lut[MJ_LUT_SIZE]; /* (length << 8) | symbol, 0 = code longer than MJ_LUT_BITS or invalid */
+    int32_t maxcode[17];       /* [len] last code of that length (right-justified), -1 if none */
+    int32_t valoff[17];        /* [len] index into vals of code 0 of that length: valptr - mincode */
+    uint8_t vals[256];
+} MjHuffDev;
+
+typedef struct {
+    uint32_t ntab;
+    uint32_t pad_[3];
+    MjHuffDev tab[MJ_MAX_TABS];
+} MjHuffSet;
+
+typedef struct {
+    uint32_t hsf, vsf;   /* sampling factors */
+    uint32_t pw, ph;     /* plane size padded to whole MCUs (decode.c:108-115) */
+    uint64_t plane_off;  /* byte offset of the plane in the batch plane buffer */
+} MjCompDev;
+
+typedef struct {
+    /* frame */
+    uint32_t X, Y, ncs, hmax, vmax;
+    uint32_t mcus_x, mcus_y, n_mcu, bpm;
+    uint32_t ri;         /* MCUs per restart interval; n_mcu when the file has no DRI */
+    uint32_t n_ivl;      /* ceil(n_mcu / ri) */
+    uint32_t sub_bits;   /* subsequence length in bits, multiple of 32 */
+    uint32_t huff_set;   /* index into the batch's MjHuffSet array */
+    uint32_t pitch;      /* RGB row pitch in bytes */
+    /* per block slot of one MCU, in scan order (decode.c:591-611) */
+    uint8_t blk_comp[MJ_MAX_BPM + 2];   /* frame component of the slot */
+    uint8_t blk_dc[MJ_MAX_BPM + 2];     /* table index (into MjHuffSet.tab) for the DC symbol */
+    uint8_t blk_ac[MJ_MAX_BPM + 2];     /* ... for AC symbols */
+    uint8_t blk_h[MJ_MAX_BPM + 2];      /* block column inside the MCU for its component */
+    uint8_t blk_v[MJ_MAX_BPM + 2];      /* block row inside the MCU */
+    MjCompDev comp[MJ_MAX_COMP];
+    uint16_t qt[MJ_MAX_COMP][64];       /* per component, natural order (quant_table.c:108-114) */
+    /* placement inside the batch buffers */
+    uint64_t raw_off;    /* entropy-coded bytes (stuffed, with RSTn) in the raw buffer */
+    uint64_t raw_len;
+    uint64_t cmp_off;    /* unstuffed, marker-free stream; 16-byte aligned */
+    uint64_t coef_off;   /* first 8x8 block in the coefficient buffer */
+    uint64_t rgb_off;    /* first byte in the RGB buffer */
+    uint32_t tile_off;   /* first scan tile; n_tiles = ceil(raw_len / MJ_SCAN_TILE) */
+    uint32_t n_tiles;
+    uint32_t ivl_off;    /* first entry in the interval-start table (n_ivl + 1 entries) */
+    uint32_t seq_off;    /* first sequence slot */
+    uint32_t seq_cap;    /* sequence slots reserved (upper bound) */
+    uint32_t wg_first;   /* first entropy workgroup of this image */
+    uint32_t multi_cap;  /* upper bound on intervals longer than one sequence */
+    uint32_t pad_;
+} MjImageDev;
+
+/* Values the scan kernels compute per image (device-written). */
+typedef struct {
+    uint32_t term_pos;   /* raw offset of the marker that ends the segment, or MJ_NO_TERMINATOR */
+    uint32_t cmp_len;    /* bytes in the compacted stream */
+    uint32_t n_rst;      /* restart markers found before the terminator */
+    uint32_t n_seq;      /* sequences laid out */
+    uint32_t status;     /* bit 0 stream overrun, bit 1 missing restart markers */
+    uint32_t pad_[3];
+} MjImageDyn;
+
+/* What a decoder knows at a symbol boundary; equal states decode identically
+ * from there on.  p is a bit offset in the image's compacted stream. */
+typedef struct {
+    uint32_t p;
+    uint32_t kc;         /* (c << 8) | k : block slot in MCU, zigzag index of next coefficient */
+} MjState;
+
+/* Result of decoding one subsequence from some entry state. */
+typedef struct {
+    MjState exit;
+    uint32_t nb;          /* blocks completed */
+    int32_t dcsum[MJ_MAX_COMP]; /* sum of DC differences decoded, per component */
+    uint32_t pad_;
+} MjSubRec;               /* 32 bytes */
+
+/* Per-sequence entry data produced by the cross-sequence fix-up. */
+typedef struct {
+    MjState entry;
+    uint32_t blk;         /* blocks of the interval that precede this sequence */
+    int32_t pred[MJ_MAX_COMP];
+    uint32_t pad_;
+} MjSeqEntry;             /* 32 bytes */
+
+#endif /* MJ_DEVICE_H */

@@ -1,0 +1,236 @@
+/*
+ * mj_emu.cpp -- host-side emulation of the entropy kernels' algorithm, lane by lane
+ * and round by round, built on the same mj_decode_span()/mj_classify() the kernels
+ * use.  It exists so the subsequence-synchronisation logic (which only the GPU runs
+ * in production) has CPU test coverage, and to measure how many synchronisation
+ * rounds real streams need.  It is not reachable from the decode entry points.
+ */
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../host/mj_host.h"
+#include "mj_entropy_core.h"
+
+namespace {
+
+struct Layout {
+    std::vector<uint8_t> cmp;         // compacted stream (+ padding)
+    std::vector<uint32_t> ivl_start;  // n_ivl + 1 byte offsets
+    uint32_t n_rst = 0;
+    uint32_t term = MJ_NO_TERMINATOR;
+};
+
+// What the scan kernels compute: unstuffed stream + interval starts.
+void emu_scan(const uint8_t *raw, size_t n, uint32_t n_ivl, Layout &L) {
+    L.cmp.clear();
+    L.ivl_start.assign(n_ivl + 1, 0);
+    uint32_t k = 0;
+    for (size_t i = 0; i < n; i++) {
+        uint32_t prev = i ? raw[i - 1] : 0, cur = raw[i], next = (i + 1 < n) ? raw[i + 1] : 0;
+        int cls = mj_classify(prev, cur, next);
+        if (cls == MJ_B_TERM) {
+            L.term = (uint32_t) i;
+            break;
+        }
+        if (cls == MJ_B_KEEP) {
+            L.cmp.push_back((uint8_t) cur);
+        } else if (cls == MJ_B_RST) {
+            k++;
+            if (k < n_ivl) {
+                L.ivl_start[k] = (uint32_t) L.cmp.size();
+            }
+        }
+    }
+    L.n_rst = k;
+    for (uint32_t j = k + 1; j <= n_ivl; j++) {
+        L.ivl_start[j] = (uint32_t) L.cmp.size();
+    }
+    L.ivl_start[n_ivl] = (uint32_t) L.cmp.size();
+    L.cmp.resize(L.cmp.size() + MJ_STREAM_PAD + 8, 0);
+    // word alignment of the buffer end
+    while (L.cmp.size() % 4) L.cmp.push_back(0);
+}
+
+struct Rec {
+    uint32_t p, k, c, nb;
+    int32_t d[4];
+};
+
+Rec span(const MjScanCtx &cx, uint32_t p, uint32_t k, uint32_t c, uint32_t end) {
+    Rec r{p, k, c, 0, {0, 0, 0, 0}};
+    mj_decode_span<false>(cx, r.p, r.k, r.c, end, r.nb, r.d[0], r.d[1], r.d[2], r.d[3], 0, 0);
+    return r;
+}
+
+bool same_state(const Rec &a, const Rec &b) {
+    return a.p == b.p && a.k == b.k && a.c == b.c;
+}
+
+}  // namespace
+
+extern "C" {
+
+/*
+ * Decode the coefficients of one JPEG file with the emulated kernel algorithm.
+ * coefs: n_blocks*64 int16 (caller-allocated, zeroed here).  force_sub_bits: 0 =
+ * the library's own choice.  stats[0] subsequences, [1] rounds summed over
+ * sequences, [2] max rounds, [3] sequences, [4] multi-sequence intervals,
+ * [5] fix-up iterations (max over intervals), [6] sub_bits used.
+ * Returns the number of blocks, or -1.
+ */
+int64_t mj_emu_decode_coefs(const uint8_t *file, size_t len, int16_t *coefs, int64_t cap_blocks, uint32_t force_sub_bits,
+                            int64_t *stats) {
+    MjParsed P;
+    const char *why = nullptr;
+    if (mj_parse_headers(file, len, &P, &why) != 0) {
+        return -1;
+    }
+    MjImageDev img;
+    MjHuffSet *set = (MjHuffSet *) calloc(1, sizeof(MjHuffSet));
+    if (mj_flatten_image(&P, len, &img, set, &why) != 0) {
+        mj_parsed_free(&P);
+        free(set);
+        return -1;
+    }
+    const int64_t n_blocks = (int64_t) img.n_mcu * img.bpm;
+    if (n_blocks > cap_blocks) {
+        mj_parsed_free(&P);
+        free(set);
+        return -1;
+    }
+    memset(coefs, 0, (size_t) n_blocks * 64 * sizeof(int16_t));
+    if (force_sub_bits) {
+        img.sub_bits = (force_sub_bits + 31) / 32 * 32;
+    }
+    const uint32_t S = img.sub_bits;
+
+    Layout L;
+    emu_scan(file + P.ent_pos, img.raw_len, img.n_ivl, L);
+
+    MjScanCtx cx;
+    cx.stream = (const uint32_t *) L.cmp.data();
+    cx.tabs = set->tab;
+    cx.coefs = coefs;
+    cx.bpm = img.bpm;
+    cx.dc_sel = mj_pack_sel(img.blk_dc, img.bpm);
+    cx.ac_sel = mj_pack_sel(img.blk_ac, img.bpm);
+    cx.comp_sel = mj_pack_sel(img.blk_comp, img.bpm);
+
+    int64_t st_subs = 0, st_rounds = 0, st_maxr = 0, st_seqs = 0, st_multi = 0, st_fix = 0;
+
+    for (uint32_t iv = 0; iv < img.n_ivl; iv++) {
+        const uint32_t b0 = L.ivl_start[iv] * 8, b1 = L.ivl_start[iv + 1] * 8;
+        const uint32_t bits = b1 - b0;
+        uint32_t nsub = (bits + S - 1) / S;
+        if (nsub == 0) nsub = 1;
+        const uint32_t nseq = (nsub + MJ_SEQ_SUBS - 1) / MJ_SEQ_SUBS;
+        st_subs += nsub;
+        st_seqs += nseq;
+        auto sub_end = [&](uint32_t j) { return (j + 1 == nsub) ? b1 : b0 + (j + 1) * S; };
+        std::vector<Rec> rec(nsub);
+
+        // ---- kernel A: one wave per sequence, lock-step rounds -------------------
+        for (uint32_t q = 0; q < nseq; q++) {
+            const uint32_t first = q * MJ_SEQ_SUBS;
+            const uint32_t n = (nsub - first < MJ_SEQ_SUBS) ? nsub - first : MJ_SEQ_SUBS;
+            std::vector<Rec> carry(n);
+            std::vector<char> active(n);
+            for (uint32_t l = 0; l < n; l++) {   // round 0: cold start
+                rec[first + l] = span(cx, b0 + (first + l) * S, 0, 0, sub_end(first + l));
+                carry[l] = rec[first + l];
+                active[l] = (l + 1 < n);
+            }
+            int64_t rounds = 0;
+            for (uint32_t r = 1; r < n; r++) {
+                bool any = false;
+                for (uint32_t l = 0; l < n; l++) any = any || active[l];
+                if (!any) break;
+                rounds++;
+                // all lanes decode "simultaneously" from their carried state ...
+                std::vector<Rec> out(n);
+                for (uint32_t l = 0; l < n; l++) {
+                    if (active[l]) {
+                        out[l] = span(cx, carry[l].p, carry[l].k, carry[l].c, sub_end(first + l + r));
+                    }
+                }
+                // ... then lane m takes what lane m-r produced for subsequence m
+                for (uint32_t l = 0; l < n; l++) {
+                    if (!active[l]) continue;
+                    const uint32_t m = l + r;
+                    const bool synced = same_state(out[l], rec[first + m]);
+                    rec[first + m] = out[l];
+                    carry[l] = out[l];
+                    if (synced || m + 1 >= n) active[l] = 0;
+                }
+            }
+            st_rounds += rounds;
+            if (rounds > st_maxr) st_maxr = rounds;
+        }
+
+        // ---- kernel B: cross-sequence fix-up (intervals longer than one sequence) --
+        if (nseq > 1) {
+            st_multi++;
+            std::vector<Rec> seen(nseq);
+            std::vector<char> have(nseq, 0);
+            int64_t iters = 0;
+            for (;;) {
+                bool changed = false;
+                iters++;
+                // phase 1: every boundary reads its entry state
+                std::vector<Rec> entry(nseq);
+                for (uint32_t q = 1; q < nseq; q++) entry[q] = rec[q * MJ_SEQ_SUBS - 1];
+                // phase 2: boundaries whose entry changed re-decode into their sequence
+                for (uint32_t q = 1; q < nseq; q++) {
+                    if (have[q] && same_state(seen[q], entry[q])) continue;
+                    seen[q] = entry[q];
+                    have[q] = 1;
+                    changed = true;
+                    Rec cur = entry[q];
+                    const uint32_t first = q * MJ_SEQ_SUBS;
+                    const uint32_t n = (nsub - first < MJ_SEQ_SUBS) ? nsub - first : MJ_SEQ_SUBS;
+                    for (uint32_t l = 0; l < n; l++) {
+                        Rec o = span(cx, cur.p, cur.k, cur.c, sub_end(first + l));
+                        const bool synced = same_state(o, rec[first + l]);
+                        rec[first + l] = o;
+                        cur = o;
+                        if (synced) break;
+                    }
+                }
+                if (!changed) break;
+            }
+            if (iters > st_fix) st_fix = iters;
+        }
+
+        // ---- prefix sums + write pass (kernel A tail / kernel D) ------------------
+        const uint32_t blk_base = iv * img.ri * img.bpm;
+        uint32_t blk_end = blk_base + img.ri * img.bpm;
+        if (blk_end > (uint32_t) n_blocks) blk_end = (uint32_t) n_blocks;
+        uint32_t blk = blk_base;
+        int32_t pred[4] = {0, 0, 0, 0};
+        for (uint32_t j = 0; j < nsub; j++) {
+            uint32_t p = j ? rec[j - 1].p : b0, k = j ? rec[j - 1].k : 0, c = j ? rec[j - 1].c : 0;
+            uint32_t nb = 0;
+            int32_t d[4] = {pred[0], pred[1], pred[2], pred[3]};
+            mj_decode_span<true>(cx, p, k, c, sub_end(j), nb, d[0], d[1], d[2], d[3], blk, blk_end);
+            // what the kernel uses: the recorded counts, not the write pass's own
+            blk += rec[j].nb;
+            for (int i = 0; i < 4; i++) pred[i] += rec[j].d[i];
+        }
+    }
+    if (stats) {
+        stats[0] = st_subs;
+        stats[1] = st_rounds;
+        stats[2] = st_maxr;
+        stats[3] = st_seqs;
+        stats[4] = st_multi;
+        stats[5] = st_fix;
+        stats[6] = S;
+        stats[7] = L.n_rst;
+    }
+    mj_parsed_free(&P);
+    free(set);
+    return n_blocks;
+}
+
+}  // extern "C"

@@ -1,0 +1,83 @@
+/*
+ * mj_internal.h -- what the C-ABI layer (mj_abi.hip) and the kernel files share:
+ * the per-batch set of device buffers and one launch function per stage.
+ */
+#ifndef MJ_INTERNAL_H
+#define MJ_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mj_device.h"
+
+/* per scan tile (MJ_SCAN_TILE raw bytes) */
+struct MjTileCnt {
+    uint32_t kept;   /* bytes that survive unstuffing, before the terminator */
+    uint32_t rst;    /* RSTn markers */
+    uint32_t term;   /* raw offset (in the image's segment) of the first terminating marker, or MJ_NO_TERMINATOR */
+    uint32_t pad_;
+};
+struct MjTileBase {
+    uint32_t kept;   /* compacted bytes before this tile */
+    uint32_t rst;    /* RSTn markers before this tile */
+};
+
+/* entropy statistics (device counters) */
+enum { MJ_ST_SUBS = 0, MJ_ST_ROUNDS, MJ_ST_MAXROUNDS, MJ_ST_SEQS, MJ_ST_MULTI, MJ_ST_FIXITERS, MJ_ST_COUNT = 8 };
+
+struct MjDeviceBatch {
+    uint32_t n_img;
+    uint32_t n_tiles;        /* scan tiles over the whole batch */
+    uint32_t n_entropy_wg;   /* entropy workgroups (4 sequences each) */
+    uint32_t n_multi_cap;    /* capacity of the multi-sequence interval list */
+    uint32_t n_idct_wg;      /* dequant+IDCT+colour workgroups */
+    uint32_t want_planes;
+
+    const MjImageDev *img;   /* [n_img] */
+    MjImageDyn *dyn;         /* [n_img] */
+    const MjHuffSet *sets;
+    const uint8_t *raw;
+    uint8_t *cmp;
+    const uint32_t *tile_img;   /* [n_tiles] image of each scan tile */
+    MjTileCnt *tile_cnt;
+    MjTileBase *tile_base;
+    uint32_t *ivl_start;     /* per image n_ivl+1 byte offsets into its compacted stream */
+    uint32_t *ivl_seq;       /* per interval: image-local index of its first sequence */
+    uint32_t *seq_ivl;       /* per sequence slot: interval (image-local) */
+    uint32_t *seq_sub;       /* per sequence slot: first subsequence within the interval */
+    MjSubRec *rec;           /* per sequence slot: 64 subsequence records */
+    MjSeqEntry *seq_entry;   /* per sequence slot */
+    MjState *seq_seen;       /* per sequence slot: entry state the fix-up last decoded from */
+    uint32_t *seq_flag;      /* per sequence slot: scratch for the fix-up */
+    uint2 *multi;            /* (image, interval) of intervals longer than one sequence */
+    uint32_t *multi_count;
+    const uint32_t *wg_img;  /* [n_entropy_wg] image of each entropy workgroup */
+    const uint32_t *idct_wg_img; /* [n_idct_wg] image of each IDCT workgroup */
+    const uint32_t *idct_wg_first; /* [n_img] first IDCT workgroup of each image */
+    int16_t *coefs;
+    uint8_t *planes;
+    uint8_t *rgb;
+    unsigned long long *stats; /* [MJ_ST_COUNT] */
+};
+
+/* Stage launchers; all asynchronous on `s`.  Return hipSuccess or the launch error. */
+hipError_t mj_launch_scan(const MjDeviceBatch &b, hipStream_t s);
+hipError_t mj_launch_entropy(const MjDeviceBatch &b, hipStream_t s);
+hipError_t mj_launch_entropy_fix(const MjDeviceBatch &b, hipStream_t s);
+hipError_t mj_launch_entropy_serial(const MjDeviceBatch &b, hipStream_t s);
+hipError_t mj_launch_idct_colour(const MjDeviceBatch &b, hipStream_t s);
+
+/* tile geometry of the IDCT kernel for one image (host + device) */
+#define MJ_IDCT_THREADS 256
+#define MJ_IDCT_MAX_BLOCKS 192
+static inline __host__ __device__ uint32_t mj_idct_tiles_x(uint32_t mcus_x, uint32_t bpm) {
+    uint32_t tmax = MJ_IDCT_MAX_BLOCKS / bpm;
+    if (tmax > 64) tmax = 64;
+    return (mcus_x + tmax - 1) / tmax;
+}
+static inline __host__ __device__ uint32_t mj_idct_tile_mcus(uint32_t mcus_x, uint32_t bpm) {
+    uint32_t tx = mj_idct_tiles_x(mcus_x, bpm);
+    return (mcus_x + tx - 1) / tx;
+}
+
+#endif

@@ -1,0 +1,287 @@
+/*
+ * mj_k_scan.hip -- the byte-level front end of the entropy stage, on the GPU.
+ *
+ * Replaces, for the whole entropy-coded segment at once, what the reference does a
+ * byte at a time inside its bit reader: stepping over the 00 stuffed after a data FF
+ * (next_byte_for_bits, bitstream.c:22-59), noticing RSTn / end markers
+ * (check_marker, bitstream.c:84-134) and jumping past RSTn
+ * (next_byte_restart_marker, bitstream.c:142-176).
+ *
+ *   mj_k_scan_count   per 4 KiB tile: surviving bytes, RSTn count, first end marker
+ *   mj_k_scan_prefix  per image: exclusive prefix over its tiles
+ *   mj_k_scan_write   per tile: write the unstuffed, marker-free stream and the byte
+ *                     offset at which every restart interval starts in it
+ *   mj_k_layout       per image: cut every interval into subsequences of sub_bits
+ *                     bits and groups of 64 subsequences (one wavefront each)
+ *
+ * All four are streaming byte kernels: HBM/L2-bound, no MFMA, ~0.25 B per pixel.
+ */
+#include "mj_entropy_core.h"
+#include "mj_internal.h"
+
+namespace {
+
+constexpr int TPB = 256;
+static_assert(TPB * 16 == MJ_SCAN_TILE, "one thread per 16 raw bytes");
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+/* exclusive scan over the 256 threads of a block; *total gets the block sum */
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *s_w /*[4]*/, uint32_t *total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t inc = wave_incl_scan(v);
+    __syncthreads();
+    if (lane == 63) s_w[w] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < TPB / 64; i++) {
+        uint32_t t = s_w[i];
+        if (i < w) base += t;
+        tot += t;
+    }
+    *total = tot;
+    return base + inc - v;
+}
+
+/* Classes of this thread's 16 bytes, 2 bits each (MJ_B_*).  Bytes at or past the
+ * end of the segment are reported as MJ_B_DROP. */
+__device__ __forceinline__ uint32_t classify16(const uint8_t *seg, uint32_t len, uint32_t pos) {
+    if (pos >= len) {
+        return 0x55555555u; /* all DROP */
+    }
+    const uint4 v = *reinterpret_cast<const uint4 *>(seg + pos);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t prev = pos ? seg[pos - 1] : 0u;
+    uint32_t after = (pos + 16 < len) ? seg[pos + 16] : 0u;
+    uint32_t cls = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const uint32_t cur = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+        uint32_t next = (i < 15) ? ((w[(i + 1) >> 2] >> (8 * ((i + 1) & 3))) & 0xFFu) : after;
+        if (pos + i + 1 >= len) next = 0;
+        uint32_t c = (pos + i < len) ? (uint32_t) mj_classify(prev, cur, next) : (uint32_t) MJ_B_DROP;
+        cls |= c << (2 * i);
+        prev = cur;
+    }
+    return cls;
+}
+
+__global__ __launch_bounds__(TPB) void mj_k_scan_count(MjDeviceBatch b) {
+    __shared__ uint32_t s_term;
+    __shared__ uint32_t s_sum[2];
+    const uint32_t tile = blockIdx.x;
+    const uint32_t ii = b.tile_img[tile];
+    const MjImageDev &im = b.img[ii];
+    const uint32_t len = (uint32_t) im.raw_len;
+    const uint8_t *seg = b.raw + im.raw_off;
+    const uint32_t pos = (tile - im.tile_off) * MJ_SCAN_TILE + threadIdx.x * 16;
+    if (threadIdx.x == 0) {
+        s_term = MJ_NO_TERMINATOR;
+        s_sum[0] = s_sum[1] = 0;
+    }
+    __syncthreads();
+    const uint32_t cls = classify16(seg, len, pos);
+    /* first terminating marker in the tile */
+    uint32_t my_term = MJ_NO_TERMINATOR;
+#pragma unroll
+    for (int i = 15; i >= 0; i--) {
+        if (((cls >> (2 * i)) & 3u) == MJ_B_TERM) my_term = pos + i;
+    }
+    if (my_term != MJ_NO_TERMINATOR) atomicMin(&s_term, my_term);
+    __syncthreads();
+    const uint32_t term = s_term;
+    uint32_t kept = 0, rst = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const uint32_t c = (cls >> (2 * i)) & 3u;
+        const bool live = pos + i < term;
+        kept += (live && c == MJ_B_KEEP);
+        rst += (live && c == MJ_B_RST);
+    }
+    /* block sums: wave reduce then LDS atomics (4 waves) */
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        kept += __shfl_xor(kept, d, 64);
+        rst += __shfl_xor(rst, d, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&s_sum[0], kept);
+        atomicAdd(&s_sum[1], rst);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        MjTileCnt c;
+        c.kept = s_sum[0];
+        c.rst = s_sum[1];
+        c.term = term;
+        c.pad_ = 0;
+        b.tile_cnt[tile] = c;
+    }
+}
+
+__global__ __launch_bounds__(TPB) void mj_k_scan_prefix(MjDeviceBatch b) {
+    __shared__ uint32_t s_w[TPB / 64];
+    __shared__ uint32_t s_term;
+    const uint32_t ii = blockIdx.x;
+    const MjImageDev &im = b.img[ii];
+    const MjTileCnt *cnt = b.tile_cnt + im.tile_off;
+    MjTileBase *base = b.tile_base + im.tile_off;
+    if (threadIdx.x == 0) s_term = MJ_NO_TERMINATOR;
+    __syncthreads();
+    uint32_t t = MJ_NO_TERMINATOR;
+    for (uint32_t i = threadIdx.x; i < im.n_tiles; i += TPB) t = min(t, cnt[i].term);
+    if (t != MJ_NO_TERMINATOR) atomicMin(&s_term, t);
+    __syncthreads();
+    const uint32_t term = s_term;
+    uint32_t carry_k = 0, carry_r = 0;
+    for (uint32_t i0 = 0; i0 < im.n_tiles; i0 += TPB) {
+        const uint32_t i = i0 + threadIdx.x;
+        uint32_t k = 0, r = 0;
+        if (i < im.n_tiles && (uint64_t) i * MJ_SCAN_TILE < term) {
+            k = cnt[i].kept;
+            r = cnt[i].rst;
+        }
+        uint32_t tk, tr;
+        const uint32_t ek = block_excl_scan(k, s_w, &tk);
+        const uint32_t er = block_excl_scan(r, s_w, &tr);
+        if (i < im.n_tiles) {
+            MjTileBase o;
+            o.kept = carry_k + ek;
+            o.rst = carry_r + er;
+            base[i] = o;
+        }
+        carry_k += tk;
+        carry_r += tr;
+    }
+    if (threadIdx.x == 0) {
+        MjImageDyn d;
+        d.term_pos = term;
+        d.cmp_len = carry_k;
+        d.n_rst = carry_r;
+        d.n_seq = 0;
+        d.status = 0;
+        d.pad_[0] = d.pad_[1] = d.pad_[2] = 0;
+        b.dyn[ii] = d;
+    }
+}
+
+__global__ __launch_bounds__(TPB) void mj_k_scan_write(MjDeviceBatch b) {
+    __shared__ uint32_t s_w[TPB / 64];
+    const uint32_t tile = blockIdx.x;
+    const uint32_t ii = b.tile_img[tile];
+    const MjImageDev &im = b.img[ii];
+    const uint32_t term = b.dyn[ii].term_pos;
+    const uint32_t tile_pos = (tile - im.tile_off) * MJ_SCAN_TILE;
+    if (tile_pos >= term) return; /* whole block: nothing of this tile survives */
+    const uint32_t len = (uint32_t) im.raw_len;
+    const uint8_t *seg = b.raw + im.raw_off;
+    const uint32_t pos = tile_pos + threadIdx.x * 16;
+    const uint32_t cls = classify16(seg, len, pos);
+    uint32_t kept = 0, rst = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const uint32_t c = (cls >> (2 * i)) & 3u;
+        const bool live = pos + i < term;
+        kept += (live && c == MJ_B_KEEP);
+        rst += (live && c == MJ_B_RST);
+    }
+    uint32_t total;
+    const uint32_t ex = block_excl_scan(kept | (rst << 16), s_w, &total);
+    const MjTileBase tb = b.tile_base[tile];
+    uint32_t out = tb.kept + (ex & 0xFFFFu);
+    uint32_t ridx = tb.rst + (ex >> 16);
+    if (pos >= len) return;
+    uint8_t *dst = b.cmp + im.cmp_off;
+    uint32_t *ivl = b.ivl_start + im.ivl_off;
+    const uint4 v = *reinterpret_cast<const uint4 *>(seg + pos);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const uint32_t c = (cls >> (2 * i)) & 3u;
+        if (pos + i >= term) break;
+        if (c == MJ_B_KEEP) {
+            dst[out++] = (uint8_t) ((w[i >> 2] >> (8 * (i & 3))) & 0xFFu);
+        } else if (c == MJ_B_RST) {
+            ridx++;
+            if (ridx < im.n_ivl) ivl[ridx] = out; /* interval ridx starts at the next surviving byte */
+        }
+    }
+}
+
+/* Per image: interval table tail, then the subsequence / sequence layout. */
+__global__ __launch_bounds__(TPB) void mj_k_layout(MjDeviceBatch b) {
+    __shared__ uint32_t s_w[TPB / 64];
+    const uint32_t ii = blockIdx.x;
+    const MjImageDev &im = b.img[ii];
+    MjImageDyn &dy = b.dyn[ii];
+    uint32_t *ivl = b.ivl_start + im.ivl_off;
+    uint32_t *ivl_seq = b.ivl_seq + im.ivl_off;
+    const uint32_t cmp_len = dy.cmp_len;
+    const uint32_t n_rst = dy.n_rst;
+    const uint32_t S = im.sub_bits;
+    /* interval 0 starts at 0; intervals whose RSTn never came are empty */
+    for (uint32_t k = threadIdx.x; k <= im.n_ivl; k += TPB) {
+        if (k == 0) ivl[0] = 0;
+        else if (k > n_rst || k == im.n_ivl) ivl[k] = cmp_len;
+    }
+    __syncthreads();
+    uint32_t carry = 0;
+    uint32_t status = (n_rst + 1 < im.n_ivl) ? 2u : 0u;
+    for (uint32_t i0 = 0; i0 < im.n_ivl; i0 += TPB) {
+        const uint32_t iv = i0 + threadIdx.x;
+        uint32_t nseq = 0, nsub = 0;
+        if (iv < im.n_ivl) {
+            const uint32_t a = ivl[iv], e = ivl[iv + 1];
+            const uint32_t bits = (e > a) ? (e - a) * 8u : 0u;
+            nsub = (bits + S - 1) / S;
+            if (nsub == 0) nsub = 1;
+            nseq = (nsub + MJ_SEQ_SUBS - 1) / MJ_SEQ_SUBS;
+        }
+        uint32_t tot;
+        const uint32_t first = carry + block_excl_scan(nseq, s_w, &tot);
+        if (iv < im.n_ivl) {
+            ivl_seq[iv] = first;
+            for (uint32_t q = 0; q < nseq; q++) {
+                if (first + q < im.seq_cap) {
+                    b.seq_ivl[im.seq_off + first + q] = iv;
+                    b.seq_sub[im.seq_off + first + q] = q * MJ_SEQ_SUBS;
+                }
+            }
+            if (nseq > 1) {
+                const uint32_t slot = atomicAdd(b.multi_count, 1u);
+                if (slot < b.n_multi_cap) b.multi[slot] = make_uint2(ii, iv);
+            }
+            atomicAdd(&b.stats[MJ_ST_SUBS], (unsigned long long) nsub);
+        }
+        carry += tot;
+    }
+    if (threadIdx.x == 0) {
+        if (carry > im.seq_cap) {
+            status |= 1u;
+            carry = im.seq_cap;
+        }
+        dy.n_seq = carry;
+        dy.status = status;
+        atomicAdd(&b.stats[MJ_ST_SEQS], (unsigned long long) carry);
+    }
+}
+
+}  // namespace
+
+hipError_t mj_launch_scan(const MjDeviceBatch &b, hipStream_t s) {
+    if (b.n_tiles == 0 || b.n_img == 0) return hipSuccess;
+    hipLaunchKernelGGL(mj_k_scan_count, dim3(b.n_tiles), dim3(TPB), 0, s, b);
+    hipLaunchKernelGGL(mj_k_scan_prefix, dim3(b.n_img), dim3(TPB), 0, s, b);
+    hipLaunchKernelGGL(mj_k_scan_write, dim3(b.n_tiles), dim3(TPB), 0, s, b);
+    hipLaunchKernelGGL(mj_k_layout, dim3(b.n_img), dim3(TPB), 0, s, b);
+    return hipGetLastError();
+}

@@ -1,0 +1,272 @@
+/*
+ * flatten.c -- from the reference's parsed structs to device descriptors.
+ *
+ * mj_parse_headers() is the marker walk of decode.c:160-415 restricted to what a
+ * baseline scan needs; it drives the same segment parsers the reference calls
+ * (decode_frame_header, decode_huff_tables, decode_quant_table,
+ * decode_restart_interval, decode_scan_header).  Where the reference then calls
+ * decode_scan() (decode.c:333), this library records where the entropy-coded
+ * bytes start and hands them to the GPU.
+ */
+#include <stdlib.h>
+#include <string.h>
+
+#include "mj_host.h"
+
+static int fail(const char **why, const char *msg) {
+    if (why) {
+        *why = msg;
+    }
+    return -1;
+}
+
+int mj_parse_headers(const uint8_t *buf, size_t len, MjParsed *out, const char **why) {
+    memset(out, 0, sizeof *out);
+    out->fh.process = (Encoding) -1; /* jpeg_decoder.c:54 */
+    Bitstream bs = {(uint8_t *) buf, 0, 0};
+    const uint8_t *end = buf + len;
+    while (bs.encoded_data + 1 < end) {
+        if (next_byte(&bs) != 0xFF) {
+            continue;
+        }
+        uint8_t m = get_byte(&bs);
+        if (m == 0xFF) {
+            continue; /* fill byte before a marker */
+        }
+        next_byte(&bs);
+        if (m == 0x00 || m == 0x01 || m == 0xD8 || (m >= 0xD0 && m <= 0xD7)) {
+            continue; /* stand-alone markers */
+        }
+        if (m == 0xD9) {
+            break;
+        }
+        if (bs.encoded_data + 2 > end) {
+            return fail(why, "truncated segment header");
+        }
+        size_t seglen = ((size_t) bs.encoded_data[0] << 8) | bs.encoded_data[1];
+        uint8_t *seg = bs.encoded_data;
+        if (seglen < 2 || seg + seglen > end) {
+            return fail(why, "segment length runs past the end of the file");
+        }
+        switch (m) {
+            case 0xC0: /* SOF0 baseline */
+            case 0xC1: /* SOF1 extended sequential, handled like baseline (decode.c:187-201) */
+                if (out->have_fh) {
+                    free_frame_header(&out->fh);
+                }
+                if (decode_frame_header(m == 0xC0 ? BDCT : ESDCTHC, &bs, &out->fh) != 0) {
+                    return fail(why, "bad frame header");
+                }
+                out->have_fh = 1;
+                break;
+            case 0xC2: case 0xC3: case 0xC5: case 0xC6: case 0xC7: case 0xC9: case 0xCA: case 0xCB:
+            case 0xCD: case 0xCE: case 0xCF:
+                return fail(why, "not a baseline sequential Huffman JPEG (progressive/lossless/arithmetic)");
+            case 0xC4:
+                if (!out->have_hts) {
+                    new_huff_tables(out->fh.process, &out->hts); /* decode.c:273-279 */
+                    out->have_hts = 1;
+                }
+                if (decode_huff_tables(&bs, &out->hts) != 0) {
+                    return fail(why, "bad Huffman table segment");
+                }
+                break;
+            case 0xDB:
+                if (decode_quant_table(&bs, &out->qts) != 0) {
+                    return fail(why, "bad quantisation table segment");
+                }
+                out->have_qts = 1;
+                break;
+            case 0xDD:
+                if (decode_restart_interval(&bs, &out->ri) != 0) {
+                    return fail(why, "bad restart interval segment");
+                }
+                break;
+            case 0xDC:
+                if (out->have_fh) {
+                    decode_number_of_lines(&bs, &out->fh);
+                }
+                break;
+            case 0xDA:
+                if (!out->have_fh) {
+                    return fail(why, "scan before frame header");
+                }
+                if (!out->have_qts) {
+                    return fail(why, "scan without a quantisation table"); /* decode.c:321-326 */
+                }
+                if (!out->have_hts) {
+                    return fail(why, "scan without a Huffman table");
+                }
+                if (decode_scan_header(&bs, &out->sh) != 0) {
+                    return fail(why, "bad scan header");
+                }
+                out->ent_pos = (size_t) (seg + seglen - buf);
+                return 0;
+            default:
+                break; /* APPn (decode.c:385), COM and the rest: skipped by length */
+        }
+        bs.encoded_data = seg + seglen;
+        bs.offset = 0;
+    }
+    return fail(why, "no scan found");
+}
+
+void mj_parsed_free(MjParsed *p) {
+    if (p->have_fh) {
+        free_frame_header(&p->fh);
+    }
+    if (p->have_hts) {
+        free_huff_tables(&p->hts);
+    }
+    memset(p, 0, sizeof *p);
+}
+
+void mj_flatten_huff(const HuffTable *ht, MjHuffDev *out) {
+    memset(out, 0, sizeof *out);
+    out->maxcode[0] = -1;
+    int nvals = 0;
+    for (int l = 1; l <= 16; l++) {
+        int n = ht->len[l - 1];
+        if (n == 0 || ht->symbols[l - 1] == NULL) {
+            out->maxcode[l] = -1;
+            out->valoff[l] = 0;
+            continue;
+        }
+        int mincode = (uint16_t) ht->min_codes[l - 1];
+        out->maxcode[l] = mincode + n - 1;
+        out->valoff[l] = nvals - mincode;
+        for (int i = 0; i < n && nvals < 256; i++, nvals++) {
+            uint8_t sym = ht->symbols[l - 1][i];
+            out->vals[nvals] = sym;
+            if (l <= MJ_LUT_BITS) {
+                /* every LUT index whose leading l bits are this code */
+                uint32_t first = (uint32_t) (mincode + i) << (MJ_LUT_BITS - l);
+                uint32_t count = 1u << (MJ_LUT_BITS - l);
+                for (uint32_t j = 0; j < count && first + j < MJ_LUT_SIZE; j++) {
+                    out->lut[first + j] = (uint16_t) ((l << 8) | sym);
+                }
+            }
+        }
+    }
+}
+
+static uint32_t pad_up(uint32_t v, uint32_t unit) {
+    return (v % unit) ? v + unit - (v % unit) : v;
+}
+
+uint32_t mj_choose_sub_bits(uint64_t raw_len, uint32_t n_ivl) {
+    uint64_t bits = raw_len * 8;
+    uint64_t avg = bits / (n_ivl ? n_ivl : 1);
+    if (avg > (uint64_t) MJ_SEQ_SUBS * 4096) {
+        return 1024; /* long intervals: many sequences per interval, short subsequences */
+    }
+    /* one wavefront per interval with a little headroom for uneven intervals */
+    uint64_t s = (avg + avg / 16 + MJ_SEQ_SUBS - 1) / MJ_SEQ_SUBS;
+    s = (s + 31) / 32 * 32;
+    if (s < 128) s = 128;
+    if (s > 4096) s = 4096;
+    return (uint32_t) s;
+}
+
+int mj_flatten_image(const MjParsed *p, size_t file_len, MjImageDev *img, MjHuffSet *set, const char **why) {
+    memset(img, 0, sizeof *img);
+    memset(set, 0, sizeof *set);
+    const FrameHeader *fh = &p->fh;
+    const ScanHeader *sh = &p->sh;
+    if (fh->precision != 8) {
+        return fail(why, "only 8-bit samples are supported");
+    }
+    if (fh->ncs != 1 && fh->ncs != 3) {
+        return fail(why, "only grey and three-component images are supported");
+    }
+    if (sh->nics != fh->ncs) {
+        return fail(why, "only one interleaved scan per image is supported");
+    }
+    if (fh->X == 0 || fh->Y == 0) {
+        return fail(why, "empty frame");
+    }
+    img->X = fh->X;
+    img->Y = fh->Y;
+    img->ncs = fh->ncs;
+    uint8_t hmax = 0, vmax = 0;
+    for (int i = 0; i < fh->ncs; i++) {
+        const Component *c = &fh->cs[i];
+        if (c->hsf < 1 || c->hsf > 4 || c->vsf < 1 || c->vsf > 4 || c->qtid > 3) {
+            return fail(why, "bad sampling factor or quantiser selector");
+        }
+        if (c->hsf > hmax) hmax = c->hsf;
+        if (c->vsf > vmax) vmax = c->vsf;
+    }
+    img->hmax = hmax;
+    img->vmax = vmax;
+    for (int i = 0; i < fh->ncs; i++) {
+        const Component *c = &fh->cs[i];
+        if (hmax % c->hsf || vmax % c->vsf) {
+            return fail(why, "sampling factors that do not divide the maximum are not supported");
+        }
+        img->comp[i].hsf = c->hsf;
+        img->comp[i].vsf = c->vsf;
+        img->comp[i].pw = pad_up(c->x, 8u * c->hsf);  /* decode.c:108-113 */
+        img->comp[i].ph = pad_up(c->y, 8u * c->vsf);
+        memcpy(img->qt[i], p->qts.tables[c->qtid].table, sizeof img->qt[i]);
+    }
+    /* MCU grid from the first scan component, as write_mcu does (decode.c:475-479) */
+    img->mcus_x = img->comp[0].pw / (8 * img->comp[0].hsf);
+    img->mcus_y = img->comp[0].ph / (8 * img->comp[0].vsf);
+    for (int i = 1; i < fh->ncs; i++) {
+        if (img->comp[i].pw / (8 * img->comp[i].hsf) != img->mcus_x ||
+            img->comp[i].ph / (8 * img->comp[i].vsf) != img->mcus_y) {
+            return fail(why, "components disagree on the MCU grid");
+        }
+    }
+    img->n_mcu = img->mcus_x * img->mcus_y;
+
+    /* block slots of one MCU in scan order, and the Huffman tables they use */
+    uint32_t bpm = 0;
+    int dc_slot[4] = {-1, -1, -1, -1}, ac_slot[4] = {-1, -1, -1, -1};
+    for (int s = 0; s < sh->nics; s++) {
+        int ci = -1;
+        for (int j = 0; j < fh->ncs; j++) {
+            if (fh->cs[j].id == sh->ics[s].sc) { /* decode.c:595-604 */
+                ci = j;
+                break;
+            }
+        }
+        if (ci < 0) {
+            return fail(why, "scan names an unknown component");
+        }
+        int td = sh->ics[s].dc, ta = sh->ics[s].ac;
+        if (td > 3 || ta > 3) {
+            return fail(why, "bad Huffman table selector");
+        }
+        if (dc_slot[td] < 0) {
+            dc_slot[td] = (int) set->ntab;
+            mj_flatten_huff(&p->hts.DCAC[TC_DC][td], &set->tab[set->ntab++]);
+        }
+        if (ac_slot[ta] < 0) {
+            ac_slot[ta] = (int) set->ntab;
+            mj_flatten_huff(&p->hts.DCAC[TC_AC][ta], &set->tab[set->ntab++]);
+        }
+        const Component *c = &fh->cs[ci];
+        for (int v = 0; v < c->vsf; v++) {
+            for (int h = 0; h < c->hsf; h++) {
+                if (bpm >= MJ_MAX_BPM) {
+                    return fail(why, "more than 10 blocks per MCU");
+                }
+                img->blk_comp[bpm] = (uint8_t) ci;
+                img->blk_dc[bpm] = (uint8_t) dc_slot[td];
+                img->blk_ac[bpm] = (uint8_t) ac_slot[ta];
+                img->blk_h[bpm] = (uint8_t) h;
+                img->blk_v[bpm] = (uint8_t) v;
+                bpm++;
+            }
+        }
+    }
+    img->bpm = bpm;
+    img->ri = p->ri ? p->ri : img->n_mcu;
+    img->n_ivl = (img->n_mcu + img->ri - 1) / img->ri;
+    img->raw_len = file_len - p->ent_pos;
+    img->sub_bits = mj_choose_sub_bits(img->raw_len, img->n_ivl);
+    img->pitch = (3 * img->X + 3u) & ~3u; /* rows start 4-byte aligned */
+    return 0;
+}

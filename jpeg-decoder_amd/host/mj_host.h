@@ -1,0 +1,48 @@
+/*
+ * mj_host.h -- internal host-side interface between the marker walk (decode_host.c),
+ * the table flattening (flatten.c) and the HIP side (csrc/).
+ */
+#ifndef MJ_HOST_H
+#define MJ_HOST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "mi355jpeg_compat.h"
+#include "../csrc/mj_device.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Everything the marker walk collects up to and including the first SOS. */
+typedef struct {
+    FrameHeader fh;
+    ScanHeader sh;
+    HuffTables hts;
+    QuantTables qts;
+    RestartInterval ri;
+    int have_fh, have_hts, have_qts;
+    size_t ent_pos;   /* offset of the first entropy-coded byte in the file */
+} MjParsed;
+
+/* decode.c:160-415: walk the markers of one file with the segment parsers and stop
+ * after the scan header.  0 / -1; on failure *why names the reason. */
+int mj_parse_headers(const uint8_t *buf, size_t len, MjParsed *out, const char **why);
+void mj_parsed_free(MjParsed *p);
+
+/* huff_table.h:9-14 -> lookup form. */
+void mj_flatten_huff(const HuffTable *ht, MjHuffDev *out);
+
+/* Geometry, per-slot table selection, quantiser tables and the Huffman set of one
+ * image.  Batch placement fields are left zero.  0 / -1. */
+int mj_flatten_image(const MjParsed *p, size_t file_len, MjImageDev *img, MjHuffSet *set, const char **why);
+
+/* Subsequence length (bits, multiple of 32) for an entropy segment of raw_len
+ * bytes split into n_ivl restart intervals. */
+uint32_t mj_choose_sub_bits(uint64_t raw_len, uint32_t n_ivl);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

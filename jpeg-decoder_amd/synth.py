@@ -1,0 +1,81 @@
+"""Deterministic synthetic inputs: the benchmark's image recipe and a baseline JPEG
+encoder (synth/jpeg_synth.c, built as libmjsynth.so)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+
+SAMPLING = {"4:4:4": (1, 1), "4:2:2": (2, 1), "4:2:0": (2, 2), "4:4:0": (1, 2), "4:1:1": (4, 1)}
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        path = os.path.join(_HERE, "libmjsynth.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} missing: run __graft_entry__.build() (make -C jpeg-decoder_amd)")
+        _lib = C.CDLL(path)
+        _lib.mjs_encode.restype = C.c_int64
+        _lib.mjs_encode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    C.c_void_p, C.c_size_t]
+    return _lib
+
+
+def synth_image(width, height, seed, sigma=12.0, grey=False):
+    """base = [255x/(W-1), 255y/(H-1), 255(x+y)/(W+H-2)] + N(0, sigma) per channel,
+    clipped to u8, numpy.random.default_rng(seed)."""
+    rng = np.random.default_rng(seed)
+    x = np.arange(width, dtype=np.float32)[None, :]
+    y = np.arange(height, dtype=np.float32)[:, None]
+    img = np.empty((height, width, 3), np.float32)
+    img[..., 0] = 255.0 * x / max(width - 1, 1)
+    img[..., 1] = 255.0 * y / max(height - 1, 1)
+    img[..., 2] = 255.0 * (x + y) / max(width + height - 2, 1)
+    img += rng.standard_normal(img.shape, dtype=np.float32) * np.float32(sigma)
+    out = np.clip(img, 0, 255).astype(np.uint8)
+    return np.ascontiguousarray(out[..., 0]) if grey else out
+
+
+def encode_jpeg(pixels, sampling="4:2:0", quality=85, restart_interval=0):
+    """Baseline SOF0 JPEG bytes for an (H, W, 3) RGB or (H, W) grey uint8 array.
+    restart_interval is in MCUs; 0 means no DRI segment."""
+    lib = _load()
+    a = np.ascontiguousarray(pixels, np.uint8)
+    if a.ndim == 2:
+        ncomp, (hs, vs) = 1, (1, 1)
+    else:
+        assert a.ndim == 3 and a.shape[2] == 3
+        ncomp, (hs, vs) = 3, SAMPLING[sampling]
+    h, w = a.shape[:2]
+    cap = w * h * ncomp + (1 << 16)
+    for _ in range(2):
+        out = np.empty(cap, np.uint8)
+        n = lib.mjs_encode(a.ctypes.data, w, h, ncomp, hs, vs, int(quality), int(restart_interval),
+                           out.ctypes.data, cap)
+        if n < 0:
+            raise ValueError("mjs_encode: bad arguments")
+        if n <= cap:
+            return out[:n].tobytes()
+        cap = int(n)
+    raise RuntimeError("mjs_encode: buffer sizing failed")
+
+
+def mcus_per_row(width, sampling="4:2:0", grey=False):
+    hs = 1 if grey else SAMPLING[sampling][0]
+    return (width + 8 * hs - 1) // (8 * hs)
+
+
+def config_jpeg(config, seed):
+    """The BASELINE configurations by name: 'C1', 'C2', 'C3', 'C4'."""
+    if config == "C1":
+        return encode_jpeg(synth_image(512, 512, seed), "4:2:0", 85, 0)
+    if config == "C2":
+        return encode_jpeg(synth_image(1920, 1080, seed), "4:4:4", 85, mcus_per_row(1920, "4:4:4"))
+    if config == "C3":
+        return encode_jpeg(synth_image(3840, 2160, seed), "4:2:0", 85, mcus_per_row(3840, "4:2:0"))
+    if config == "C4":
+        return encode_jpeg(synth_image(7680, 4320, seed), "4:2:0", 85, 0)
+    raise KeyError(config)

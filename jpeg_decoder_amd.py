@@ -1,0 +1,12 @@
+"""Import alias: the package directory is named ``jpeg-decoder_amd`` (not a valid
+Python identifier), so ``import jpeg_decoder_amd`` loads it from there."""
+import importlib.util
+import os
+import sys
+
+_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "jpeg-decoder_amd")
+_spec = importlib.util.spec_from_file_location(
+    __name__, os.path.join(_dir, "__init__.py"), submodule_search_locations=[_dir])
+_mod = importlib.util.module_from_spec(_spec)
+sys.modules[__name__] = _mod
+_spec.loader.exec_module(_mod)

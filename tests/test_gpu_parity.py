@@ -1,0 +1,217 @@
+"""GPU parity: the HIP path, called through the C ABI, against (a) the committed
+reference outputs in tests/golden and (b) the CPU restatement in oracle/ on seeded
+synthetic inputs.  Bar: coefficients, planes and RGB bit-exact (the north star asks
+for +-1 on RGB; the kernels reproduce the reference's rounding points, so the tests
+ask for 0 and would report the max error)."""
+import ctypes as C
+import hashlib
+
+import numpy as np
+import pytest
+
+import jpeg_decoder_amd as J
+from jpeg_decoder_amd import binding
+from conftest import PARITY_FIXTURES, load_fixture
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    c = J.Context(0)
+    yield c
+    c.close()
+
+
+def _check_image(b, i, coefs, planes, rgb, what):
+    assert b.status(i) == 0, f"{what}: status {b.status(i)}"
+    got = b.coefs(i)
+    assert got.shape == coefs.shape, what
+    bad = np.nonzero((got != coefs).any(axis=1))[0]
+    assert bad.size == 0, f"{what}: {bad.size} coefficient blocks differ, first {bad[:5]}"
+    if planes is not None:
+        for c, p in enumerate(planes):
+            assert np.array_equal(b.plane(i, c), p), f"{what}: plane {c} differs"
+    out = b.rgb(i)
+    err = np.abs(out.astype(int) - rgb.astype(int)).max() if out.size else 0
+    assert err == 0, f"{what}: RGB max abs error {err}"
+
+
+@pytest.mark.parametrize("flags", [0, binding.MJ_ENTROPY_SERIAL])
+def test_golden_fixtures_one_mixed_batch(ctx, flags):
+    """All fixtures (grey, 4:2:0, 4:2:2, 4:4:4; DRI on/off; optimised tables;
+    custom quantisers) in ONE batch, against the reference's committed outputs."""
+    files, golds = [], []
+    for name in PARITY_FIXTURES:
+        d, g = load_fixture(name)
+        files.append(d)
+        golds.append(g)
+    b = ctx.batch(files, binding.MJ_WANT_PLANES | flags)
+    b.decode()
+    b.sync()
+    for i, (name, g) in enumerate(zip(PARITY_FIXTURES, golds)):
+        planes = [g[f"plane{c}"] for c in range(3) if f"plane{c}" in g]
+        _check_image(b, i, g["coefs"], planes, g["rgb"], name)
+    b.close()
+
+
+@pytest.mark.parametrize("name", PARITY_FIXTURES)
+def test_golden_fixture_alone_and_twice(ctx, name):
+    """Each fixture as a batch of one, decoded twice (idempotence of a resident batch)."""
+    d, g = load_fixture(name)
+    b = ctx.batch([d], 0)
+    for _ in range(2):
+        b.decode()
+        b.sync()
+        _check_image(b, 0, g["coefs"], None, g["rgb"], name)
+    b.close()
+
+
+def test_last_mcu_divergence_is_decoded_by_count(ctx, oracle):
+    """The reference drops a final MCU that starts in the last entropy byte
+    (decode.c:578-589); the GPU path decodes by MCU count like the restatement."""
+    d, g = load_fixture("g_flat_32x8_refdrops")
+    b = ctx.batch([d], 0)
+    b.decode()
+    o = oracle.decode(d)
+    assert np.array_equal(b.coefs(0), o.coefs)
+    assert np.array_equal(b.coefs(0)[:3], g["coefs"])
+    assert np.array_equal(b.rgb(0), o.rgb)
+    b.close()
+
+
+SYNTH_CASES = [
+    # (w, h, sampling, quality, restart interval in MCUs, grey)
+    (200, 120, "4:2:0", 85, 0, False),
+    (200, 120, "4:2:0", 50, 13, False),      # intervals that straddle MCU rows
+    (333, 77, "4:2:2", 95, 21, False),       # width/height not MCU multiples
+    (131, 260, "4:4:4", 75, 17, False),
+    (96, 200, "4:4:0", 85, 12, False),       # 1x2 sampling (not producible by the fixture encoder)
+    (256, 64, "4:1:1", 85, 8, False),        # 4x1 sampling
+    (640, 480, None, 50, 0, True),           # grey, BASELINE config 5
+    (640, 480, "4:2:2", 95, 0, False),
+    (640, 480, "4:2:0", 75, 40, False),
+    (48, 16, "4:2:0", 90, 1, False),         # one MCU per interval
+]
+
+
+@pytest.mark.parametrize("case", SYNTH_CASES, ids=lambda c: f"{c[0]}x{c[1]}_{c[2]}_q{c[3]}_ri{c[4]}")
+def test_synthetic_vs_oracle(ctx, oracle, case):
+    w, h, samp, q, ri, grey = case
+    img = J.synth.synth_image(w, h, seed=w * 7 + h, grey=grey)
+    data = J.synth.encode_jpeg(img, samp or "4:4:4", q, ri)
+    o = oracle.decode(data)
+    b = ctx.batch([data], binding.MJ_WANT_PLANES)
+    b.decode()
+    _check_image(b, 0, o.coefs, o.planes, o.rgb, str(case))
+    b.close()
+
+
+def test_no_restart_long_scan_cross_sequence(ctx, oracle):
+    """A scan without restart markers that spans many sequences: exercises the
+    cross-sequence fix-up and the second write kernel."""
+    data = J.synth.encode_jpeg(J.synth.synth_image(1024, 768, 3), "4:2:0", 85, 0)
+    o = oracle.decode(data)
+    b = ctx.batch([data], 0)
+    b.decode()
+    st = b.entropy_stats()
+    assert st["multi_seq_intervals"] == 1 and st["sequences"] > 4, st
+    _check_image(b, 0, o.coefs, None, o.rgb, "1024x768 no-RST")
+    b.close()
+
+
+@pytest.mark.parametrize("config", ["C1", "C2", "C3"])
+def test_baseline_configs_vs_oracle(ctx, oracle, config):
+    """BASELINE configs at full size, one image each, bit-exact against the restatement."""
+    data = J.synth.config_jpeg(config, seed=1)
+    o = oracle.decode(data)
+    b = ctx.batch([data], 0)
+    b.decode()
+    _check_image(b, 0, o.coefs, None, o.rgb, config)
+    b.close()
+
+
+def test_config4_8k_no_restart(ctx, oracle):
+    """8K 4:2:0 without restart markers (129,600 MCUs, one interval).  The reference
+    itself misplaces blocks past 65,535 MCUs (decode.h:15), so pixels are checked
+    against the restatement, whose MCU counter is 32-bit."""
+    data = J.synth.config_jpeg("C4", seed=0)
+    o = oracle.decode(data)
+    b = ctx.batch([data], 0)
+    b.decode()
+    _check_image(b, 0, o.coefs, None, o.rgb, "C4")
+    b.close()
+
+
+def test_batch_is_order_independent_and_matches_single(ctx):
+    """Size-independent property at BASELINE shape: an image decodes to the same bytes
+    alone, in a batch, and at another position of the batch."""
+    files = [J.synth.config_jpeg("C3", seed=s) for s in range(3)]
+    files.append(J.synth.config_jpeg("C2", seed=9))
+    b = ctx.batch(files, 0)
+    b.decode()
+    digests = [hashlib.sha256(b.rgb(i).tobytes()).hexdigest() for i in range(len(files))]
+    cdig = [hashlib.sha256(b.coefs(i).tobytes()).hexdigest() for i in range(len(files))]
+    b.close()
+    b2 = ctx.batch(files[::-1], 0)
+    b2.decode()
+    n = len(files)
+    for i in range(n):
+        assert hashlib.sha256(b2.rgb(n - 1 - i).tobytes()).hexdigest() == digests[i]
+        assert hashlib.sha256(b2.coefs(n - 1 - i).tobytes()).hexdigest() == cdig[i]
+    b2.close()
+    b3 = ctx.batch([files[1]], 0)
+    b3.decode()
+    assert hashlib.sha256(b3.rgb(0).tobytes()).hexdigest() == digests[1]
+    b3.close()
+
+
+class _Component(C.Structure):
+    _fields_ = [("id", C.c_uint8), ("hsf", C.c_uint8), ("vsf", C.c_uint8), ("x", C.c_uint16), ("y", C.c_uint16),
+                ("qtid", C.c_uint8)]
+
+
+class _FrameHeader(C.Structure):
+    _fields_ = [("process", C.c_int), ("precision", C.c_uint8), ("X", C.c_uint16), ("Y", C.c_uint16),
+                ("ncs", C.c_uint8), ("cs", C.POINTER(_Component))]
+
+
+class _Image(C.Structure):
+    _fields_ = [("buf", C.POINTER(C.POINTER(C.c_uint8))), ("width", C.POINTER(C.c_int)), ("mcu", C.c_uint16),
+                ("n_du", C.c_uint8)]
+
+
+@pytest.mark.parametrize("name", ["c420_q85_100x75_ri3", "c444_q75_opt_57x43", "g_q95_opt_120x88_rirow",
+                                  "C1_c420_q85_512x512"])
+def test_dropin_api_like_the_reference_viewer(ctx, name):
+    """decode_jpeg_buffer + ycbcr_rgb/y_rgb + free_img, called the way the reference's
+    main() calls them (jpeg_decoder.c:52-104), with a pitch wider than 3*width."""
+    lib = J.load_library()
+    data, g = load_fixture(name)
+    buf = C.create_string_buffer(data, len(data) + 16)
+    fh = _FrameHeader()
+    fh.process = -1
+    img = C.POINTER(_Image)()
+    lib.decode_jpeg_buffer.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(_FrameHeader), C.POINTER(C.POINTER(_Image))]
+    assert lib.decode_jpeg_buffer(buf, len(data), C.byref(fh), C.byref(img)) == 0
+    H, W = g["rgb"].shape[:2]
+    assert (fh.X, fh.Y) == (W, H)
+    for c in range(fh.ncs):
+        p = g[f"plane{c}"]
+        got = np.ctypeslib.as_array(img.contents.buf[c], shape=p.shape)
+        assert img.contents.width[c] == p.shape[1]
+        assert np.array_equal(got, p), f"Image.buf[{c}] differs"
+    pitch = 3 * W + 8
+    pixels = np.zeros((H, pitch), np.uint8)
+    fn = lib.y_rgb if fh.ncs == 1 else lib.ycbcr_rgb
+    fn.argtypes = [C.POINTER(_FrameHeader), C.POINTER(_Image), C.c_void_p, C.c_uint16, C.c_uint16, C.c_uint16]
+    assert fn(C.byref(fh), img, pixels.ctypes.data, W, H, pitch) == 0
+    assert np.array_equal(pixels[:, :3 * W].reshape(H, W, 3), g["rgb"])
+    assert not pixels[:, 3 * W:].any(), "bytes beyond the row were touched"
+    lib.free_img.argtypes = [C.POINTER(_Image)]
+    lib.free_img.restype = None
+    lib.free_img(img)
+    lib.free_frame_header.argtypes = [C.POINTER(_FrameHeader)]
+    lib.free_frame_header(C.byref(fh))
