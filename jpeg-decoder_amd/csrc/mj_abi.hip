@@ -313,6 +313,9 @@ static int batch_build(mj_ctx *ctx, std::vector<MjPrepared> &prep, uint32_t flag
     d.n_multi_cap = (uint32_t) n_multi;
     d.n_idct_wg = (uint32_t) n_idct;
     d.want_planes = (flags & MJ_WANT_PLANES) ? 1u : 0u;
+    d.dbg = (flags >> 16) & 0xFFu;
+    d.max_ntab = 1;
+    for (const MjHuffSet &hs : b->sets) d.max_ntab = hs.ntab > d.max_ntab ? hs.ntab : d.max_ntab;
     b->coef_bytes = coef_blocks * 128;
     b->rgb_bytes = rgb_total;
     b->plane_bytes = plane_total;
@@ -380,8 +383,10 @@ int mj_batch_decode(mj_batch *b) {
     HIP_TRY(mark(0));
     HIP_TRY(hipMemsetAsync(b->d.stats, 0, MJ_ST_COUNT * sizeof(unsigned long long), s));
     HIP_TRY(hipMemsetAsync(b->d.multi_count, 0, 16, s));
-    /* the block decoder only stores non-zero coefficients (decode.c:612 zeroes each block first) */
-    HIP_TRY(hipMemsetAsync(b->d.coefs, 0, b->coef_bytes ? b->coef_bytes : 16, s));
+    if (b->flags & MJ_ENTROPY_SERIAL) {
+        /* the diagnostic decoder stores only non-zero coefficients (decode.c:612 zeroes each block first) */
+        HIP_TRY(hipMemsetAsync(b->d.coefs, 0, b->coef_bytes ? b->coef_bytes : 16, s));
+    }
     HIP_TRY(mark(1));
     HIP_TRY(mj_launch_scan(b->d, s));
     HIP_TRY(mark(2));
@@ -393,6 +398,7 @@ int mj_batch_decode(mj_batch *b) {
         HIP_TRY(mj_launch_entropy(b->d, s));
         HIP_TRY(mark(3));
         HIP_TRY(mj_launch_entropy_fix(b->d, s));
+        HIP_TRY(mj_launch_entropy_write(b->d, s));
         HIP_TRY(mark(4));
     }
     HIP_TRY(mj_launch_idct_colour(b->d, s));

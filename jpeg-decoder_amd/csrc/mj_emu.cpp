@@ -202,19 +202,35 @@ int64_t mj_emu_decode_coefs(const uint8_t *file, size_t len, int16_t *coefs, int
             if (iters > st_fix) st_fix = iters;
         }
 
-        // ---- prefix sums + write pass (kernel A tail / kernel D) ------------------
+        // ---- prefix sums + write pass (mj_k_entropy_write) --------------------------
         const uint32_t blk_base = iv * img.ri * img.bpm;
         uint32_t blk_end = blk_base + img.ri * img.bpm;
         if (blk_end > (uint32_t) n_blocks) blk_end = (uint32_t) n_blocks;
-        uint32_t blk = blk_base;
+        uint32_t blk0 = blk_base;
         int32_t pred[4] = {0, 0, 0, 0};
         for (uint32_t j = 0; j < nsub; j++) {
             uint32_t p = j ? rec[j - 1].p : b0, k = j ? rec[j - 1].k : 0, c = j ? rec[j - 1].c : 0;
-            uint32_t nb = 0;
+            uint32_t blk = blk0;
             int32_t d[4] = {pred[0], pred[1], pred[2], pred[3]};
-            mj_decode_span<true>(cx, p, k, c, sub_end(j), nb, d[0], d[1], d[2], d[3], blk, blk_end);
+            bool skip = (k != 0);
+            int16_t buf[64];
+            memset(buf, 0, sizeof buf);
+            const uint32_t end = sub_end(j);
+            if (mj_write_live(p, k, skip, end, b1)) {
+                MjBits bw;
+                mj_bits_init(bw, cx.stream, p);
+                while (mj_write_live(p, k, skip, end, b1)) {
+                    bool fin = false;
+                    uint32_t fin_blk = 0;
+                    mj_write_step(cx, bw, p, k, c, skip, blk, blk_end, d[0], d[1], d[2], d[3], buf, fin, fin_blk);
+                    if (fin) {
+                        memcpy(coefs + (size_t) fin_blk * 64, buf, sizeof buf);
+                        memset(buf, 0, sizeof buf);
+                    }
+                }
+            }
             // what the kernel uses: the recorded counts, not the write pass's own
-            blk += rec[j].nb;
+            blk0 += rec[j].nb;
             for (int i = 0; i < 4; i++) pred[i] += rec[j].d[i];
         }
     }

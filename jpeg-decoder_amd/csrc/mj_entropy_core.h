@@ -1,10 +1,10 @@
 /*
  * mj_entropy_core.h -- the symbol-level Huffman decoder shared by the entropy
  * kernels (HIP, one lane per subsequence) and by the host-side emulation used in
- * the CPU tests.  One function, mj_decode_span(), decodes from a given state up to
- * a bit position; it is what decode_data_unit() (decode.c:665-723) plus the bit
- * reader (bitstream.c:61-78) do, restated over an unstuffed, marker-free stream
- * and restartable at any symbol boundary.
+ * the CPU tests.  mj_step() decodes one symbol; it is what decode_data_unit()
+ * (decode.c:665-723) plus the bit reader (bitstream.c:61-78) do per symbol,
+ * restated over an unstuffed, marker-free stream and restartable at any symbol
+ * boundary.  mj_decode_span() runs it from a given state up to a bit position.
  */
 #ifndef MJ_ENTROPY_CORE_H
 #define MJ_ENTROPY_CORE_H
@@ -42,16 +42,112 @@ MJ_HD uint64_t mj_pack_sel(const uint8_t *v, uint32_t n) {
     return r;
 }
 
+/* Bit window over the stream: the next `avail` (>= 33 after a refill) bits are the
+ * top bits of buf.  nxt_raw is the following word, loaded one refill ahead and left
+ * byte-swapped-later so that the load's latency overlaps several symbols. */
+struct MjBits {
+    uint64_t buf;
+    int32_t avail;
+    uint32_t wi;
+    uint32_t nxt_raw;
+};
+
+MJ_HD void mj_bits_init(MjBits &bw, const uint32_t *stream, uint32_t p) {
+    uint32_t wi = p >> 5;
+    bw.buf = (((uint64_t) mj_be32(stream[wi]) << 32) | mj_be32(stream[wi + 1])) << (p & 31);
+    bw.avail = 64 - (int32_t) (p & 31);
+    bw.wi = wi + 2;
+    bw.nxt_raw = stream[bw.wi];
+}
+
+MJ_HD void mj_bits_refill(MjBits &bw, const uint32_t *stream) {
+    if (bw.avail <= 32) {
+        bw.buf |= (uint64_t) mj_be32(bw.nxt_raw) << (32 - bw.avail);
+        bw.avail += 32;
+        bw.wi++;
+        bw.nxt_raw = stream[bw.wi];
+    }
+}
+
+/* What one symbol did. */
+struct MjSym {
+    int32_t val;      /* DC difference, or AC coefficient value */
+    uint32_t kpos;    /* zigzag position the value belongs to (0 for DC) */
+    uint32_t comp;    /* component, valid when dc */
+    bool dc;          /* the symbol was the block's DC */
+    bool store;       /* val is a coefficient to store (DC always; AC when size != 0 and in range) */
+    bool done;        /* the block ended with this symbol */
+};
+
 /*
- * Decode symbols from state (p, k, c) until p >= end.
- *   p   bit offset in the stream; k  zigzag index of the next coefficient (0 = the
+ * Decode one symbol at state (p, k, c) and advance the state.
+ *   p  bit offset in the stream; k  zigzag index of the next coefficient (0: the
  *   block's DC symbol comes next); c  block slot inside the MCU.
- * nb is advanced by the number of blocks completed.  d0..d3 are per-component DC
- * accumulators: every DC difference is added to its component's accumulator
- * (decode.c:682-690; the int16 wrap is applied when the value is stored).  With
- * WRITE, coefficients are stored for blocks blk <= index < blk_end, where blk is
- * the block the entry state is in; the caller supplies zero-filled blocks
- * (decode.c:612) and the accumulators must hold the predictors on entry.
+ * The caller has refilled bw (mj_bits_refill) since the previous step.
+ */
+MJ_HD MjSym mj_step(const MjScanCtx &cx, MjBits &bw, uint32_t &p, uint32_t &k, uint32_t &c) {
+    MjSym s;
+    const bool isac = (k != 0);
+    const uint32_t t = (uint32_t) ((isac ? cx.ac_sel : cx.dc_sel) >> (4 * c)) & 15u;
+    const MjHuffDev *T = cx.tabs + t;
+    const uint32_t w = (uint32_t) (bw.buf >> 48);
+    const uint32_t e = T->lut[w >> (16 - MJ_LUT_BITS)];
+    uint32_t len = e >> 8, sym = e & 255u;
+    if (len == 0) {
+        /* code longer than the direct table: canonical ranges per length
+         * (the reference compares against max_codes per length, decode.c:674-681) */
+        len = 16;
+        sym = 0;
+        for (uint32_t L = MJ_LUT_BITS + 1; L <= 16; L++) {
+            const int32_t code = (int32_t) (w >> (16 - L));
+            if (code <= T->maxcode[L]) {
+                sym = T->vals[(uint32_t) (T->valoff[L] + code) & 255u];
+                len = L;
+                break;
+            }
+        }
+    }
+    const uint32_t size = sym & 15u;
+    const uint32_t rest = (uint32_t) ((bw.buf << len) >> 32);
+    const uint32_t mag = size ? (rest >> (32 - size)) : 0u;
+    /* EXTEND (decode.c:684-686, :716-718) */
+    s.val = (size && mag < (1u << (size - 1))) ? (int32_t) mag - (int32_t) (1u << size) + 1 : (int32_t) mag;
+    const uint32_t used = len + size;
+    bw.buf <<= used;
+    bw.avail -= (int32_t) used;
+    p += used;
+    s.dc = !isac;
+    s.comp = (uint32_t) (cx.comp_sel >> (4 * c)) & 15u;
+    if (!isac) {
+        s.kpos = 0;
+        s.store = true;
+        k = 1;
+    } else if (sym == 0) {
+        s.kpos = 0;
+        s.store = false;
+        k = 64; /* EOB */
+    } else {
+        k += sym >> 4; /* run; ZRL (0xF0) has size 0 and nets +16 */
+        s.kpos = k;
+        s.store = (size != 0) && (k < 64);
+        k += 1;
+    }
+    s.done = (k >= 64);
+    if (s.done) {
+        k = 0;
+        c = (c + 1 == cx.bpm) ? 0 : c + 1;
+    }
+    return s;
+}
+
+/*
+ * Decode symbols from state (p, k, c) until p >= end.  nb is advanced by the number
+ * of blocks completed.  d0..d3 are per-component DC accumulators: every DC
+ * difference is added to its component's accumulator (decode.c:682-690; the int16
+ * wrap is applied when the value is stored).  With WRITE, coefficients are stored
+ * straight to cx.coefs for blocks blk <= index < blk_end, where blk is the block the
+ * entry state is in; the caller supplies zero-filled blocks (decode.c:612) and the
+ * accumulators must hold the predictors on entry.
  */
 template <bool WRITE>
 MJ_HD void mj_decode_span(const MjScanCtx &cx, uint32_t &p, uint32_t &k, uint32_t &c, uint32_t end, uint32_t &nb,
@@ -59,74 +155,74 @@ MJ_HD void mj_decode_span(const MjScanCtx &cx, uint32_t &p, uint32_t &k, uint32_
     if (p >= end) {
         return;
     }
-    uint32_t wi = p >> 5;
-    uint64_t buf = ((uint64_t) mj_be32(cx.stream[wi]) << 32) | mj_be32(cx.stream[wi + 1]);
-    buf <<= (p & 31);
-    int32_t avail = 64 - (int32_t) (p & 31);
-    wi += 2;
-    uint32_t nxt = mj_be32(cx.stream[wi]);
+    MjBits bw;
+    mj_bits_init(bw, cx.stream, p);
     while (p < end) {
-        if (avail <= 32) {
-            buf |= (uint64_t) nxt << (32 - avail);
-            avail += 32;
-            wi++;
-            nxt = mj_be32(cx.stream[wi]);
-        }
-        const bool isac = (k != 0);
-        const uint32_t t = (uint32_t) ((isac ? cx.ac_sel : cx.dc_sel) >> (4 * c)) & 15u;
-        const MjHuffDev *T = cx.tabs + t;
-        const uint32_t w = (uint32_t) (buf >> 48);
-        uint32_t e = T->lut[w >> (16 - MJ_LUT_BITS)];
-        uint32_t len = e >> 8, sym = e & 255u;
-        if (len == 0) {
-            /* code longer than the direct table: canonical ranges per length */
-            len = 16;
-            sym = 0;
-            for (uint32_t L = MJ_LUT_BITS + 1; L <= 16; L++) {
-                int32_t code = (int32_t) (w >> (16 - L));
-                if (code <= T->maxcode[L]) {
-                    sym = T->vals[(uint32_t) (T->valoff[L] + code) & 255u];
-                    len = L;
-                    break;
-                }
-            }
-        }
-        const uint32_t size = sym & 15u;
-        const uint32_t rest = (uint32_t) ((buf << len) >> 32);
-        const uint32_t mag = size ? (rest >> (32 - size)) : 0u;
-        /* EXTEND (decode.c:684-686, :716-718) */
-        const int32_t val = (size && mag < (1u << (size - 1))) ? (int32_t) mag - (int32_t) (1u << size) + 1 : (int32_t) mag;
-        const uint32_t used = len + size;
-        buf <<= used;
-        avail -= (int32_t) used;
-        p += used;
-        if (!isac) {
-            const uint32_t comp = (uint32_t) (cx.comp_sel >> (4 * c)) & 15u;
-            d0 += (comp == 0) ? val : 0;
-            d1 += (comp == 1) ? val : 0;
-            d2 += (comp == 2) ? val : 0;
-            d3 += (comp == 3) ? val : 0;
+        mj_bits_refill(bw, cx.stream);
+        const MjSym s = mj_step(cx, bw, p, k, c);
+        if (s.dc) {
+            d0 += (s.comp == 0) ? s.val : 0;
+            d1 += (s.comp == 1) ? s.val : 0;
+            d2 += (s.comp == 2) ? s.val : 0;
+            d3 += (s.comp == 3) ? s.val : 0;
             if (WRITE && blk < blk_end) {
-                const int32_t dc = (comp == 0) ? d0 : (comp == 1) ? d1 : (comp == 2) ? d2 : d3;
+                const int32_t dc = (s.comp == 0) ? d0 : (s.comp == 1) ? d1 : (s.comp == 2) ? d2 : d3;
                 cx.coefs[(uint64_t) blk * 64] = (int16_t) dc;
             }
-            k = 1;
-        } else if (sym == 0) {
-            k = 64; /* EOB */
-        } else {
-            k += sym >> 4; /* run; ZRL (0xF0) has size 0 and nets +16 */
-            if (WRITE && size && k < 64 && blk < blk_end) {
-                cx.coefs[(uint64_t) blk * 64 + k] = (int16_t) val;
-            }
-            k += 1;
+        } else if (WRITE && s.store && blk < blk_end) {
+            cx.coefs[(uint64_t) blk * 64 + s.kpos] = (int16_t) s.val;
         }
-        if (k >= 64) {
-            k = 0;
-            c = (c + 1 == cx.bpm) ? 0 : c + 1;
+        if (s.done) {
             nb++;
             blk++;
         }
     }
+}
+
+/*
+ * One step of the writing pass of one lane.  The lane assembles the block it is in
+ * inside blkbuf (64 int16, zero-filled by the caller) and reports `fin` when the
+ * block is complete and should be copied to block index fin_blk of the image.
+ *
+ * Ownership: a block belongs to the lane that decodes its DC symbol.  A lane whose
+ * entry state is in the middle of a block (k != 0) runs in `skip` mode until that
+ * block ends -- the previous lane finishes it by decoding past its own subsequence
+ * end (see mj_write_live) -- so every block is assembled by exactly one lane and
+ * leaves the chip as one full 128-byte line.
+ */
+MJ_HD void mj_write_step(const MjScanCtx &cx, MjBits &bw, uint32_t &p, uint32_t &k, uint32_t &c, bool &skip,
+                         uint32_t &blk, uint32_t blk_end, int32_t &d0, int32_t &d1, int32_t &d2, int32_t &d3,
+                         int16_t *blkbuf, bool &fin, uint32_t &fin_blk) {
+    mj_bits_refill(bw, cx.stream);
+    const MjSym s = mj_step(cx, bw, p, k, c);
+    const bool mine = !skip && blk < blk_end;
+    if (s.dc) {
+        d0 += (s.comp == 0) ? s.val : 0;
+        d1 += (s.comp == 1) ? s.val : 0;
+        d2 += (s.comp == 2) ? s.val : 0;
+        d3 += (s.comp == 3) ? s.val : 0;
+        if (mine) {
+            const int32_t dc = (s.comp == 0) ? d0 : (s.comp == 1) ? d1 : (s.comp == 2) ? d2 : d3;
+            blkbuf[0] = (int16_t) dc;
+        }
+    } else if (s.store && mine) {
+        blkbuf[s.kpos] = (int16_t) s.val;
+    }
+    fin = false;
+    if (s.done) {
+        if (mine) {
+            fin = true;
+            fin_blk = blk;
+        }
+        skip = false;
+        blk++;
+    }
+}
+
+/* Is the lane still decoding in the writing pass?  Up to its subsequence end, and
+ * beyond it while it is inside a block it owns (never past the interval's end). */
+MJ_HD bool mj_write_live(uint32_t p, uint32_t k, bool skip, uint32_t end, uint32_t hard_end) {
+    return (p < end) || (k != 0 && !skip && p < hard_end);
 }
 
 /* Byte classes of the raw entropy-coded segment (bitstream.c:22-59, :84-176). */

@@ -32,6 +32,8 @@ struct MjDeviceBatch {
     uint32_t n_multi_cap;    /* capacity of the multi-sequence interval list */
     uint32_t n_idct_wg;      /* dequant+IDCT+colour workgroups */
     uint32_t want_planes;
+    uint32_t max_ntab;       /* largest Huffman table set in the batch (sizes the kernels' LDS) */
+    uint32_t dbg;            /* timing experiments only: bit 0 skip write pass, bit 1 skip sync rounds, bit 2 skip coefficient stores */
 
     const MjImageDev *img;   /* [n_img] */
     MjImageDyn *dyn;         /* [n_img] */
@@ -64,6 +66,7 @@ struct MjDeviceBatch {
 hipError_t mj_launch_scan(const MjDeviceBatch &b, hipStream_t s);
 hipError_t mj_launch_entropy(const MjDeviceBatch &b, hipStream_t s);
 hipError_t mj_launch_entropy_fix(const MjDeviceBatch &b, hipStream_t s);
+hipError_t mj_launch_entropy_write(const MjDeviceBatch &b, hipStream_t s);
 hipError_t mj_launch_entropy_serial(const MjDeviceBatch &b, hipStream_t s);
 hipError_t mj_launch_idct_colour(const MjDeviceBatch &b, hipStream_t s);
 

@@ -19,12 +19,18 @@
  *     starts with for the final, writing pass.
  *
  * One wavefront owns one *sequence* of up to 64 consecutive subsequences of one
- * interval and runs the synchronisation rounds in lock step with cross-lane
- * shuffles; the four wavefronts of a workgroup share the image's Huffman lookup
- * tables in LDS.  An interval that fits one sequence (the restart-marker case) is
- * finished inside that one kernel.  Longer intervals (scans without restart
- * markers) go through mj_k_entropy_fix (cross-sequence synchronisation + prefix
- * over sequences) and mj_k_entropy_write.
+ * interval; the four wavefronts of a workgroup share the image's Huffman lookup
+ * tables in LDS.
+ *   mj_k_entropy_sync   cold decode + lock-step synchronisation rounds (cross-lane
+ *                       shuffles), one 32-byte record per subsequence to HBM;
+ *   mj_k_entropy_fix    only for intervals longer than one sequence (scans without
+ *                       restart markers): cross-sequence synchronisation and the
+ *                       prefix over sequences;
+ *   mj_k_entropy_write  prefix sums over the records, then the writing pass: every
+ *                       lane assembles its current block in LDS and the wavefront
+ *                       copies finished blocks out as whole 128-byte lines, so the
+ *                       coefficient buffer is written exactly once, with no
+ *                       read-modify-write and no zero-fill pass.
  *
  * The kernels are latency / issue bound (dependent LDS lookups per symbol); the
  * figure of merit is decoded bits per second, not an HBM roofline.
@@ -57,6 +63,8 @@ __device__ __forceinline__ Geo interval_geo(const uint32_t *ivl, uint32_t iv, ui
 __device__ __forceinline__ uint32_t sub_end(const Geo &g, uint32_t j, uint32_t S) {
     return (j + 1 >= g.nsub) ? g.b1 : g.b0 + (j + 1) * S;
 }
+
+extern __shared__ __align__(16) unsigned char s_dyn[];
 
 /* cooperative copy of the image's Huffman tables into LDS */
 __device__ __forceinline__ void load_tables(MjHuffDev *s_tabs, const MjHuffSet &set) {
@@ -146,7 +154,7 @@ __device__ __forceinline__ void write_pass(const MjScanCtx &cx, uint32_t p, uint
 /* and, for single-sequence intervals, prefix sums + the writing pass       */
 /* ------------------------------------------------------------------------ */
 __global__ __launch_bounds__(TPB) void mj_k_entropy_sync(MjDeviceBatch b) {
-    __shared__ MjHuffDev s_tabs[MJ_MAX_TABS];
+    MjHuffDev *s_tabs = reinterpret_cast<MjHuffDev *>(s_dyn);
     const uint32_t ii = b.wg_img[blockIdx.x];
     const MjImageDev &im = b.img[ii];
     const uint32_t n_seq = b.dyn[ii].n_seq;
@@ -178,7 +186,7 @@ __global__ __launch_bounds__(TPB) void mj_k_entropy_sync(MjDeviceBatch b) {
     bool active = valid && (lane + 1 < n);
     uint32_t rounds = 0;
     for (uint32_t r = 1; r < n; r++) {
-        if (!__any(active)) break;
+        if (!__any(active) || (b.dbg & 2u)) break;
         rounds++;
         LaneRec out = rec;
         if (active) out = decode_nowrite(cx, carry_p, carry_kc, sub_end(g, j + r, S));
@@ -202,34 +210,17 @@ __global__ __launch_bounds__(TPB) void mj_k_entropy_sync(MjDeviceBatch b) {
         atomicMax(&b.stats[MJ_ST_MAXROUNDS], (unsigned long long) rounds);
     }
 
-    if (g.nseq > 1) {
-        /* long interval: hand the records to the cross-sequence fix-up */
-        MjSubRec o;
-        o.exit.p = rec.p;
-        o.exit.kc = rec.kc;
-        o.nb = valid ? rec.nb : 0;
-        o.dcsum[0] = valid ? rec.d0 : 0;
-        o.dcsum[1] = valid ? rec.d1 : 0;
-        o.dcsum[2] = valid ? rec.d2 : 0;
-        o.dcsum[3] = valid ? rec.d3 : 0;
-        o.pad_ = 0;
-        b.rec[(uint64_t) (im.seq_off + seq) * MJ_SEQ_SUBS + lane] = o;
-        return;
-    }
-
-    /* single-sequence interval: entry state = previous lane's exit; prefix sums */
-    uint32_t ep = __shfl_up(rec.p, 1, 64), ekc = __shfl_up(rec.kc, 1, 64);
-    if (lane == 0) {
-        ep = g.b0;
-        ekc = 0;
-    }
-    uint32_t nb = valid ? rec.nb : 0;
-    int32_t d0 = valid ? rec.d0 : 0, d1 = valid ? rec.d1 : 0, d2 = valid ? rec.d2 : 0, d3 = valid ? rec.d3 : 0;
-    wave_excl_scan5(nb, d0, d1, d2, d3);
-    const uint32_t n_blocks = im.n_mcu * im.bpm;
-    const uint32_t blk_base = iv * im.ri * im.bpm;
-    const uint32_t blk_end = min(blk_base + im.ri * im.bpm, n_blocks);
-    if (valid) write_pass(cx, ep, ekc, end_own, blk_base + nb, blk_end, d0, d1, d2, d3);
+    /* one record per subsequence for the fix-up / writing kernels */
+    MjSubRec o;
+    o.exit.p = rec.p;
+    o.exit.kc = rec.kc;
+    o.nb = valid ? rec.nb : 0;
+    o.dcsum[0] = valid ? rec.d0 : 0;
+    o.dcsum[1] = valid ? rec.d1 : 0;
+    o.dcsum[2] = valid ? rec.d2 : 0;
+    o.dcsum[3] = valid ? rec.d3 : 0;
+    o.pad_ = 0;
+    b.rec[(uint64_t) (im.seq_off + seq) * MJ_SEQ_SUBS + lane] = o;
 }
 
 /* ------------------------------------------------------------------------ */
@@ -238,7 +229,7 @@ __global__ __launch_bounds__(TPB) void mj_k_entropy_sync(MjDeviceBatch b) {
 constexpr int FIX_TPB = 1024;
 
 __global__ __launch_bounds__(FIX_TPB) void mj_k_entropy_fix(MjDeviceBatch b) {
-    __shared__ MjHuffDev s_tabs[MJ_MAX_TABS];
+    MjHuffDev *s_tabs = reinterpret_cast<MjHuffDev *>(s_dyn);
     __shared__ int s_changed;
     __shared__ uint32_t s_part[FIX_TPB * 5];
     const uint32_t n_multi = min(*b.multi_count, b.n_multi_cap);
@@ -374,52 +365,113 @@ __global__ __launch_bounds__(FIX_TPB) void mj_k_entropy_fix(MjDeviceBatch b) {
 }
 
 /* ------------------------------------------------------------------------ */
-/* kernel 3: writing pass for the sequences of long intervals               */
+/* kernel 3: writing pass, all sequences                                    */
 /* ------------------------------------------------------------------------ */
+constexpr int BLK_STRIDE = 144;   /* bytes per lane block buffer: 128 + 16, conflict-free 16-byte reads */
+
 __global__ __launch_bounds__(TPB) void mj_k_entropy_write(MjDeviceBatch b) {
-    __shared__ MjHuffDev s_tabs[MJ_MAX_TABS];
+    /* dynamic LDS: [tables][block buffers: TPB x 144 B][flush lists: TPB x (4 + 4) B] */
+    MjHuffDev *s_tabs = reinterpret_cast<MjHuffDev *>(s_dyn);
+    unsigned char *s_blk = s_dyn + b.max_ntab * sizeof(MjHuffDev);
+    uint32_t *s_list_blk = reinterpret_cast<uint32_t *>(s_blk + TPB * BLK_STRIDE);
+    uint32_t *s_list_lane = s_list_blk + TPB;
+
     const uint32_t ii = b.wg_img[blockIdx.x];
     const MjImageDev &im = b.img[ii];
     const uint32_t n_seq = b.dyn[ii].n_seq;
     const uint32_t seq0 = (blockIdx.x - im.wg_first) * WAVES;
     if (seq0 >= n_seq) return;
-    const uint32_t S = im.sub_bits;
-    /* does any of this workgroup's sequences belong to a long interval? */
-    bool any_long = false;
-    for (uint32_t w = 0; w < WAVES && seq0 + w < n_seq; w++) {
-        const Geo gw = interval_geo(b.ivl_start + im.ivl_off, b.seq_ivl[im.seq_off + seq0 + w], S);
-        any_long = any_long || gw.nseq > 1;
-    }
-    if (!any_long) return;
     load_tables(s_tabs, b.sets[im.huff_set]);
+    {   /* zero the block buffers */
+        uint4 *z = reinterpret_cast<uint4 *>(s_blk);
+        for (uint32_t i = threadIdx.x; i < TPB * BLK_STRIDE / 16; i += TPB) z[i] = make_uint4(0, 0, 0, 0);
+    }
     __syncthreads();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t seq = seq0 + wave;
     if (seq >= n_seq) return;
+
+    const uint32_t S = im.sub_bits;
     const uint32_t iv = b.seq_ivl[im.seq_off + seq];
     const uint32_t first = b.seq_sub[im.seq_off + seq];
     const Geo g = interval_geo(b.ivl_start + im.ivl_off, iv, S);
-    if (g.nseq <= 1) return;
     const uint32_t n = min(g.nsub - first, (uint32_t) MJ_SEQ_SUBS);
     const MjScanCtx cx = make_ctx(b, im, s_tabs);
     const bool valid = lane < n;
     const MjSubRec r = b.rec[(uint64_t) (im.seq_off + seq) * MJ_SEQ_SUBS + lane];
-    const MjSeqEntry se = b.seq_entry[im.seq_off + seq];
-    uint32_t ep = __shfl_up(r.exit.p, 1, 64), ekc = __shfl_up(r.exit.kc, 1, 64);
+
+    /* where the sequence starts: the interval start, or what the fix-up computed */
+    const uint32_t n_blocks = im.n_mcu * im.bpm;
+    const uint32_t blk_base = iv * im.ri * im.bpm;
+    const uint32_t blk_end = min(blk_base + im.ri * im.bpm, n_blocks);
+    MjSeqEntry se;
+    se.entry.p = g.b0;
+    se.entry.kc = 0;
+    se.blk = blk_base;
+    se.pred[0] = se.pred[1] = se.pred[2] = se.pred[3] = 0;
+    if (g.nseq > 1) se = b.seq_entry[im.seq_off + seq];
+
+    uint32_t p = __shfl_up(r.exit.p, 1, 64), kc = __shfl_up(r.exit.kc, 1, 64);
     if (lane == 0) {
-        ep = se.entry.p;
-        ekc = se.entry.kc;
+        p = se.entry.p;
+        kc = se.entry.kc;
     }
     uint32_t nb = valid ? r.nb : 0;
     int32_t d0 = valid ? r.dcsum[0] : 0, d1 = valid ? r.dcsum[1] : 0, d2 = valid ? r.dcsum[2] : 0,
             d3 = valid ? r.dcsum[3] : 0;
+    const uint32_t own_nb = nb;
     wave_excl_scan5(nb, d0, d1, d2, d3);
-    const uint32_t n_blocks = im.n_mcu * im.bpm;
-    const uint32_t blk_end = min(iv * im.ri * im.bpm + im.ri * im.bpm, n_blocks);
-    if (valid) {
-        write_pass(cx, ep, ekc, sub_end(g, first + lane, S), se.blk + nb, blk_end, se.pred[0] + d0, se.pred[1] + d1,
-                   se.pred[2] + d2, se.pred[3] + d3);
+    /* every block of the interval must be accounted for by its last sequence */
+    if (first + n == g.nsub && lane == n - 1 && se.blk + nb + own_nb < blk_end) atomicOr(&b.dyn[ii].status, 1u);
+    if (b.dbg & 1u) return;
+
+    uint32_t k = kc & 0xFFu, c = kc >> 8;
+    uint32_t blk = se.blk + nb;
+    d0 += se.pred[0];
+    d1 += se.pred[1];
+    d2 += se.pred[2];
+    d3 += se.pred[3];
+    bool skip = (k != 0);
+    const uint32_t end = sub_end(g, first + lane, S);
+    int16_t *blkbuf = reinterpret_cast<int16_t *>(s_blk + (wave * 64 + lane) * BLK_STRIDE);
+    uint32_t *list_blk = s_list_blk + wave * 64, *list_lane = s_list_lane + wave * 64;
+    const unsigned char *wave_blk = s_blk + wave * 64 * BLK_STRIDE;
+    unsigned char *coef_bytes = reinterpret_cast<unsigned char *>(cx.coefs);
+    const uint32_t store_end = (b.dbg & 4u) ? 0u : blk_end;
+
+    MjBits bw;
+    bool live = valid && mj_write_live(p, k, skip, end, g.b1);
+    if (live) mj_bits_init(bw, cx.stream, p);
+    while (__any(live)) {
+        bool fin = false;
+        uint32_t fin_blk = 0;
+        if (live) {
+            mj_write_step(cx, bw, p, k, c, skip, blk, blk_end, d0, d1, d2, d3, blkbuf, fin, fin_blk);
+            live = mj_write_live(p, k, skip, end, g.b1);
+        }
+        const unsigned long long mask = __ballot(fin);
+        if (mask) {
+            /* finished blocks leave as whole lines: 8 lanes x 16 bytes per block */
+            const uint32_t rank = __popcll(mask & ((1ull << lane) - 1ull));
+            if (fin) {
+                list_blk[rank] = fin_blk;
+                list_lane[rank] = lane;
+            }
+            const uint32_t cnt = __popcll(mask);
+            for (uint32_t i0 = 0; i0 < cnt; i0 += 8) {
+                const uint32_t idx = i0 + (lane >> 3);
+                if (idx < cnt) {
+                    const uint32_t src_lane = list_lane[idx], dst_blk = list_blk[idx];
+                    uint4 *src = reinterpret_cast<uint4 *>(const_cast<unsigned char *>(wave_blk) + src_lane * BLK_STRIDE + (lane & 7) * 16);
+                    const uint4 v = *src;
+                    *src = make_uint4(0, 0, 0, 0);
+                    if (dst_blk < store_end) {
+                        *reinterpret_cast<uint4 *>(coef_bytes + (uint64_t) dst_blk * 128 + (lane & 7) * 16) = v;
+                    }
+                }
+            }
+        }
     }
 }
 
@@ -427,7 +479,7 @@ __global__ __launch_bounds__(TPB) void mj_k_entropy_write(MjDeviceBatch b) {
 /* diagnostic: one lane per restart interval, no subsequence machinery      */
 /* ------------------------------------------------------------------------ */
 __global__ __launch_bounds__(TPB) void mj_k_entropy_serial(MjDeviceBatch b) {
-    __shared__ MjHuffDev s_tabs[MJ_MAX_TABS];
+    MjHuffDev *s_tabs = reinterpret_cast<MjHuffDev *>(s_dyn);
     const uint32_t ii = blockIdx.x;
     const MjImageDev &im = b.img[ii];
     load_tables(s_tabs, b.sets[im.huff_set]);
@@ -444,21 +496,31 @@ __global__ __launch_bounds__(TPB) void mj_k_entropy_serial(MjDeviceBatch b) {
 
 }  // namespace
 
+static size_t table_lds(const MjDeviceBatch &b) {
+    return (size_t) b.max_ntab * sizeof(MjHuffDev);
+}
+
 hipError_t mj_launch_entropy(const MjDeviceBatch &b, hipStream_t s) {
     if (b.n_entropy_wg == 0) return hipSuccess;
-    hipLaunchKernelGGL(mj_k_entropy_sync, dim3(b.n_entropy_wg), dim3(TPB), 0, s, b);
+    hipLaunchKernelGGL(mj_k_entropy_sync, dim3(b.n_entropy_wg), dim3(TPB), table_lds(b), s, b);
     return hipGetLastError();
 }
 
 hipError_t mj_launch_entropy_fix(const MjDeviceBatch &b, hipStream_t s) {
     if (b.n_multi_cap == 0 || b.n_entropy_wg == 0) return hipSuccess;
-    hipLaunchKernelGGL(mj_k_entropy_fix, dim3(b.n_multi_cap), dim3(FIX_TPB), 0, s, b);
-    hipLaunchKernelGGL(mj_k_entropy_write, dim3(b.n_entropy_wg), dim3(TPB), 0, s, b);
+    hipLaunchKernelGGL(mj_k_entropy_fix, dim3(b.n_multi_cap), dim3(FIX_TPB), table_lds(b), s, b);
+    return hipGetLastError();
+}
+
+hipError_t mj_launch_entropy_write(const MjDeviceBatch &b, hipStream_t s) {
+    if (b.n_entropy_wg == 0) return hipSuccess;
+    const size_t lds = table_lds(b) + (size_t) TPB * BLK_STRIDE + (size_t) TPB * 8;
+    hipLaunchKernelGGL(mj_k_entropy_write, dim3(b.n_entropy_wg), dim3(TPB), lds, s, b);
     return hipGetLastError();
 }
 
 hipError_t mj_launch_entropy_serial(const MjDeviceBatch &b, hipStream_t s) {
     if (b.n_img == 0) return hipSuccess;
-    hipLaunchKernelGGL(mj_k_entropy_serial, dim3(b.n_img), dim3(TPB), 0, s, b);
+    hipLaunchKernelGGL(mj_k_entropy_serial, dim3(b.n_img), dim3(TPB), table_lds(b), s, b);
     return hipGetLastError();
 }
