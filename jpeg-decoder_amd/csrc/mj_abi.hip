@@ -272,7 +272,7 @@ static int batch_build(mj_ctx *ctx, std::vector<MjPrepared> &prep, uint32_t flag
         uint64_t mc = im.raw_len * 8 / seq_bits;
         im.multi_cap = (uint32_t) (mc < im.n_ivl ? mc : im.n_ivl);
         n_multi += im.multi_cap;
-        const uint32_t iw = im.mcus_y * mj_idct_tiles_x(im.mcus_x, im.bpm);
+        const uint32_t iw = im.mcus_y * mj_idct_tiles_x(im.mcus_x, im.bpm, im.hmax);
         idct_first[i] = (uint32_t) n_idct;
         n_idct += iw;
         tile_img.insert(tile_img.end(), im.n_tiles, (uint32_t) i);

@@ -72,14 +72,20 @@ hipError_t mj_launch_idct_colour(const MjDeviceBatch &b, hipStream_t s);
 
 /* tile geometry of the IDCT kernel for one image (host + device) */
 #define MJ_IDCT_THREADS 256
-#define MJ_IDCT_MAX_BLOCKS 192
-static inline __host__ __device__ uint32_t mj_idct_tiles_x(uint32_t mcus_x, uint32_t bpm) {
+#define MJ_IDCT_MAX_BLOCKS 256
+/* MCUs per tile: at most MJ_IDCT_MAX_BLOCKS blocks, one per thread. */
+static inline __host__ __device__ uint32_t mj_idct_tile_cap(uint32_t bpm, uint32_t hmax) {
+    (void) hmax;
     uint32_t tmax = MJ_IDCT_MAX_BLOCKS / bpm;
     if (tmax > 64) tmax = 64;
+    return tmax ? tmax : 1;
+}
+static inline __host__ __device__ uint32_t mj_idct_tiles_x(uint32_t mcus_x, uint32_t bpm, uint32_t hmax) {
+    const uint32_t tmax = mj_idct_tile_cap(bpm, hmax);
     return (mcus_x + tmax - 1) / tmax;
 }
-static inline __host__ __device__ uint32_t mj_idct_tile_mcus(uint32_t mcus_x, uint32_t bpm) {
-    uint32_t tx = mj_idct_tiles_x(mcus_x, bpm);
+static inline __host__ __device__ uint32_t mj_idct_tile_mcus(uint32_t mcus_x, uint32_t bpm, uint32_t hmax) {
+    const uint32_t tx = mj_idct_tiles_x(mcus_x, bpm, hmax);
     return (mcus_x + tx - 1) / tx;
 }
 

@@ -31,12 +31,7 @@ namespace {
 constexpr int TPB = MJ_IDCT_THREADS;
 constexpr int MAXB = MJ_IDCT_MAX_BLOCKS;
 constexpr int COEF_STRIDE = 144;               /* bytes per block in LDS: 128 + 16 pad, conflict-free b128 reads */
-constexpr int MAX_TILE_W = 64 * 8 * 4;         /* widest luma tile row in samples (T <= 64 MCUs, hmax <= 4)... */
 constexpr int PLANE_BYTES = MAXB * 64;         /* every sample of every block of the tile, all components */
-
-__constant__ uint8_t c_zz[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
-                                 41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
-                                 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
 /* compile-time zigzag table for fully unrolled register indexing */
 struct ZZ {
@@ -46,82 +41,107 @@ struct ZZ {
 };
 
 /* 8-point inverse butterfly (dct.c:296-341).  (float)(C * (double)x) is a product
- * rounded to double and then to float, as the C source's mixed types imply. */
+ * rounded to double and then to float, as the C source's mixed types imply.
+ *
+ * The reference halves after every add ("0.5 * (a + b)").  Multiplying by a power
+ * of two is exact and commutes with every rounding, so the halvings are carried as
+ * an implicit scale instead (capital letters = 2x or 4x the reference's variable)
+ * and folded into the double constants: the results are bit-identical and twelve
+ * multiplies per butterfly disappear. */
+template <bool FINAL>
 __device__ __forceinline__ void idct8(float &d0, float &d1, float &d2, float &d3, float &d4, float &d5, float &d6,
                                       float &d7) {
+    /* FINAL: the caller's next step is 0.25 * x + 128 (dct.c:192); the exact factor
+     * 0.25 is folded into the last constant as well */
+    constexpr double C = FINAL ? 0.25 * 0.707106781 : 0.707106781, C2 = 2.0 * 0.707106781;
     const float t0 = (float) (1.414213562 * (double) d0);
     const float t1 = d4, t2 = d2, t3 = d6;
-    const float t4 = 0.5f * (d1 - d7);
-    const float t5 = (float) (0.707106781 * (double) d3);
-    const float t6 = (float) (0.707106781 * (double) d5);
-    const float t7 = 0.5f * (d1 + d7);
+    const float T4 = d1 - d7;                            /* 2 t4 */
+    const float T5 = (float) (C2 * (double) d3);         /* 2 t5 */
+    const float T6 = (float) (C2 * (double) d5);         /* 2 t6 */
+    const float T7 = d1 + d7;                            /* 2 t7 */
 
-    const float u0 = 0.5f * (t0 + t1);
-    const float u1 = 0.5f * (t0 - t1);
+    const float U0 = t0 + t1;                            /* 2 u0 */
+    const float U1 = t0 - t1;                            /* 2 u1 */
     const double t2d = (double) t2, t3d = (double) t3;
-    const float u2 = (float) (0.707106781 * (0.38268343236 * t2d + -0.92387953251 * t3d));
-    const float u3 = (float) (0.707106781 * (0.92387953251 * t2d + 0.38268343236 * t3d));
-    const float u4 = 0.5f * (t4 + t6);
-    const float u5 = 0.5f * (t7 - t5);
-    const float u6 = 0.5f * (t4 - t6);
-    const float u7 = 0.5f * (t5 + t7);
+    const float U2 = (float) (C2 * (0.38268343236 * t2d + -0.92387953251 * t3d));   /* 2 u2 */
+    const float U3 = (float) (C2 * (0.92387953251 * t2d + 0.38268343236 * t3d));    /* 2 u3 */
+    const float U4 = T4 + T6;                            /* 4 u4 */
+    const float U5 = T7 - T5;                            /* 4 u5 */
+    const float U6 = T4 - T6;                            /* 4 u6 */
+    const float U7 = T5 + T7;                            /* 4 u7 */
 
-    const float w0 = 0.5f * (u0 + u3);
-    const float w1 = 0.5f * (u1 + u2);
-    const float w2 = 0.5f * (u1 - u2);
-    const float w3 = 0.5f * (u0 - u3);
-    const double u4d = (double) u4, u5d = (double) u5, u6d = (double) u6, u7d = (double) u7;
-    const float w4 = (float) (0.8314696123 * u4d + -0.55557023302 * u7d);
-    const float w5 = (float) (0.9807852804 * u5d + -0.19509032201 * u6d);
-    const float w6 = (float) (0.19509032201 * u5d + 0.9807852804 * u6d);
-    const float w7 = (float) (0.55557023302 * u4d + 0.8314696123 * u7d);
+    const float W0 = U0 + U3;                            /* 4 w0 */
+    const float W1 = U1 + U2;
+    const float W2 = U1 - U2;
+    const float W3 = U0 - U3;
+    const double u4d = (double) U4, u5d = (double) U5, u6d = (double) U6, u7d = (double) U7;
+    const float W4 = (float) (0.8314696123 * u4d + -0.55557023302 * u7d);           /* 4 w4 */
+    const float W5 = (float) (0.9807852804 * u5d + -0.19509032201 * u6d);
+    const float W6 = (float) (0.19509032201 * u5d + 0.9807852804 * u6d);
+    const float W7 = (float) (0.55557023302 * u4d + 0.8314696123 * u7d);
 
-    const double K = 1.414213562 * 2;
-    d0 = (float) (K * (double) (w0 + w7));
-    d1 = (float) (K * (double) (w1 + w6));
-    d2 = (float) (K * (double) (w2 + w5));
-    d3 = (float) (K * (double) (w3 + w4));
-    d4 = (float) (K * (double) (w3 - w4));
-    d5 = (float) (K * (double) (w2 - w5));
-    d6 = (float) (K * (double) (w1 - w6));
-    d7 = (float) (K * (double) (w0 - w7));
+    /* reference: 1.414213562 * 2 * (w + w'); here the sum carries a factor 4 */
+    d0 = (float) (C * (double) (W0 + W7));
+    d1 = (float) (C * (double) (W1 + W6));
+    d2 = (float) (C * (double) (W2 + W5));
+    d3 = (float) (C * (double) (W3 + W4));
+    d4 = (float) (C * (double) (W3 - W4));
+    d5 = (float) (C * (double) (W2 - W5));
+    d6 = (float) (C * (double) (W1 - W6));
+    d7 = (float) (C * (double) (W0 - W7));
 }
 
-/* dct.c:187-193 with CLAMP_8 (dct.c:6): 0.25*x + 128 in double, clamp, truncate */
-__device__ __forceinline__ uint32_t finish(float x) {
-    const double v = 0.25 * (double) x + 128.0;
-    const double c = (v > 255.0) ? 255.0 : ((v < 0.0) ? 0.0 : v);
-    return (uint32_t) (int32_t) c;
+/* dct.c:187-193 with CLAMP_8 (dct.c:6): clamp(0.25*x + 128) in double, then
+ * truncate.  q is 0.25*x already (see idct8<true>).  Truncating first and clamping
+ * the integer gives the same result for every finite input. */
+__device__ __forceinline__ uint32_t finish(float q) {
+    const int32_t i = (int32_t) ((double) q + 128.0);
+    return (uint32_t) min(max(i, 0), 255);
 }
 
 /* colour_conversion.c:76-79 as compiled by gcc 11.4 -O2: below zero -> 0, above
- * 256 -> 255, otherwise truncate (through a 32-bit integer) */
+ * 256 -> 255, otherwise truncate through a 32-bit integer (so exactly 256.0f, which
+ * one (Y,Cb,Cr) triple reaches in G, wraps to 0). */
 __device__ __forceinline__ uint32_t store8(float v) {
-    if (v < 0.0f) return 0u;
-    if (v > 256.0f) return 255u;
-    return (uint32_t) (int32_t) v & 0xFFu;
+    const int32_t i = (int32_t) v;
+    const uint32_t r = (uint32_t) min(max(i, 0), 255);
+    return (v == 256.0f) ? 0u : r;
 }
 
-/* colour_conversion.c:71-74: double arithmetic left to right, rounded to float */
-__device__ __forceinline__ uint32_t ycc_to_rgb24(uint32_t Y, uint32_t Cb, uint32_t Cr) {
+/* colour_conversion.c:71-74.  The products with the chroma samples come from
+ * per-workgroup LDS tables indexed by the sample value:
+ *   cr -> (1.402 * (cr - 128), 0.71414 * (cr - 128)),  cb -> (0.34414 * (cb - 128), 1.772 * (cb - 128))
+ * computed once per value in double exactly as the expression does; the adds keep
+ * the source's left-to-right order. */
+__device__ __forceinline__ uint32_t ycc_to_rgb24(uint32_t Y, const double2 tcb, const double2 tcr) {
     const double y = (double) Y;
-    const double cb = (double) (float) Cb - 128.0, cr = (double) (float) Cr - 128.0;
-    const float R = (float) (y + 1.402 * cr);
-    const float G = (float) ((y - 0.34414 * cb) - 0.71414 * cr);
-    const float B = (float) (y + 1.772 * cb);
+    const float R = (float) (y + tcr.x);
+    const float G = (float) ((y - tcb.x) - tcr.y);
+    const float B = (float) (y + tcb.y);
     return store8(R) | (store8(G) << 8) | (store8(B) << 16);
 }
 
-__global__ __launch_bounds__(TPB) void mj_k_idct_colour(MjDeviceBatch b) {
-    __shared__ __align__(16) uint8_t s_coef[MAXB * COEF_STRIDE];
-    __shared__ __align__(16) uint8_t s_plane[PLANE_BYTES];
+#ifndef MJ_IDCT_WAVES
+#define MJ_IDCT_WAVES 3
+#endif
+__global__ __launch_bounds__(TPB, MJ_IDCT_WAVES) void mj_k_idct_colour(MjDeviceBatch b) {
+    /* One LDS region used twice: first the tile's coefficients (144 B per block),
+     * then -- once every thread holds its block in registers -- the tile's sample
+     * planes (64 B per block) followed by the two chroma product tables. */
+    __shared__ __align__(16) uint8_t s_mem[MAXB * COEF_STRIDE];
     __shared__ __align__(16) uint16_t s_qt[MJ_MAX_COMP][64];
+    uint8_t *s_coef = s_mem;
+    uint8_t *s_plane = s_mem;
+    double2 *s_tcb = reinterpret_cast<double2 *>(s_mem + PLANE_BYTES);
+    double2 *s_tcr = s_tcb + 256;
+    static_assert(PLANE_BYTES + 2 * 256 * sizeof(double2) <= MAXB * COEF_STRIDE, "LDS reuse");
 
     const uint32_t ii = b.idct_wg_img[blockIdx.x];
     const MjImageDev &im = b.img[ii];
     const uint32_t bpm = im.bpm;
-    const uint32_t tiles_x = mj_idct_tiles_x(im.mcus_x, bpm);
-    const uint32_t T = mj_idct_tile_mcus(im.mcus_x, bpm);
+    const uint32_t tiles_x = mj_idct_tiles_x(im.mcus_x, bpm, im.hmax);
+    const uint32_t T = mj_idct_tile_mcus(im.mcus_x, bpm, im.hmax);
     const uint32_t wg = blockIdx.x - b.idct_wg_first[ii];
     const uint32_t mrow = wg / tiles_x;
     const uint32_t m0 = (wg % tiles_x) * T;
@@ -151,12 +171,10 @@ __global__ __launch_bounds__(TPB) void mj_k_idct_colour(MjDeviceBatch b) {
     auto pl_off = [&](uint32_t c) { return c == 0 ? po0 : (c == 1 ? po1 : po2); };
 
     /* ---- 2. one block per thread ------------------------------------------ */
-    if (threadIdx.x < nblk) {
-        const uint32_t t = threadIdx.x / bpm, slot = threadIdx.x % bpm;
-        const uint32_t comp = im.blk_comp[slot];
-        const uint16_t *q = s_qt[comp];
+    const bool has_block = threadIdx.x < nblk;
+    uint32_t zw[32];
+    if (has_block) {
         const uint4 *cz = reinterpret_cast<const uint4 *>(s_coef + threadIdx.x * COEF_STRIDE);
-        uint32_t zw[32];
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             const uint4 v = cz[i];
@@ -165,6 +183,17 @@ __global__ __launch_bounds__(TPB) void mj_k_idct_colour(MjDeviceBatch b) {
             zw[4 * i + 2] = v.z;
             zw[4 * i + 3] = v.w;
         }
+    }
+    __syncthreads();   /* every block is in registers: the region becomes planes + tables */
+    {
+        const double v = (double) (float) threadIdx.x - 128.0;   /* TPB == 256 sample values */
+        s_tcb[threadIdx.x] = make_double2(0.34414 * v, 1.772 * v);
+        s_tcr[threadIdx.x] = make_double2(1.402 * v, 0.71414 * v);
+    }
+    if (has_block && !(b.dbg & 16u)) {
+        const uint32_t t = threadIdx.x / bpm, slot = threadIdx.x % bpm;
+        const uint32_t comp = im.blk_comp[slot];
+        const uint16_t *q = s_qt[comp];
         float c[64];
 #pragma unroll
         for (int i = 0; i < 64; i++) {
@@ -181,14 +210,14 @@ __global__ __launch_bounds__(TPB) void mj_k_idct_colour(MjDeviceBatch b) {
         }
 #pragma unroll
         for (int r = 0; r < 8; r++) {
-            idct8(c[8 * r + 0], c[8 * r + 1], c[8 * r + 2], c[8 * r + 3], c[8 * r + 4], c[8 * r + 5], c[8 * r + 6],
-                  c[8 * r + 7]);
+            idct8<false>(c[8 * r + 0], c[8 * r + 1], c[8 * r + 2], c[8 * r + 3], c[8 * r + 4], c[8 * r + 5], c[8 * r + 6],
+                         c[8 * r + 7]);
         }
         /* second pass down the columns (the reference transposes, runs rows, and
          * transposes back on the store: dct.c:173-193) */
 #pragma unroll
         for (int x = 0; x < 8; x++) {
-            idct8(c[x], c[8 + x], c[16 + x], c[24 + x], c[32 + x], c[40 + x], c[48 + x], c[56 + x]);
+            idct8<true>(c[x], c[8 + x], c[16 + x], c[24 + x], c[32 + x], c[40 + x], c[48 + x], c[56 + x]);
         }
         const uint32_t x0 = (t * im.comp[comp].hsf + im.blk_h[slot]) * 8, y0 = im.blk_v[slot] * 8u;
         uint8_t *dst = s_plane + pl_off(comp) + y0 * pl_w(comp) + x0;
@@ -216,15 +245,26 @@ __global__ __launch_bounds__(TPB) void mj_k_idct_colour(MjDeviceBatch b) {
         }
     }
 
+    if (b.dbg & 8u) return;
     /* ---- 3. upsample + colour, 4 pixels (12 bytes) per thread per step ----- */
+    /* The tile's quads (4 horizontally adjacent pixels) are numbered row-major; a
+     * thread takes quad tid, tid + TPB, ... and tracks (row, quad-in-row)
+     * incrementally, so the loop has no division. */
     const uint32_t tile_w = nm * im.hmax * 8, tile_h = im.vmax * 8;
     const uint32_t px0 = m0 * im.hmax * 8, py0 = mrow * tile_h;
     const uint32_t quads = tile_w / 4;
+    const uint32_t dy = TPB / quads, dq = TPB - dy * quads;
+    uint32_t y = threadIdx.x / quads;
+    uint32_t qx = threadIdx.x - y * quads;
     uint8_t *rgb = b.rgb + im.rgb_off;
     if (im.ncs == 1) {
-        for (uint32_t i = threadIdx.x; i < quads * tile_h; i += TPB) {
-            const uint32_t y = i / quads, x = (i % quads) * 4;
-            const uint32_t gy = py0 + y, gx = px0 + x;
+        for (; y < tile_h; y += dy, qx += dq) {
+            if (qx >= quads) {
+                qx -= quads;
+                y++;
+                if (y >= tile_h) break;
+            }
+            const uint32_t x = qx * 4, gy = py0 + y, gx = px0 + x;
             if (gy >= im.Y || gx >= im.X) continue;
             const uint32_t v = *reinterpret_cast<const uint32_t *>(s_plane + y * pw0 + x);
             const uint32_t a = v & 0xFF, bb = (v >> 8) & 0xFF, cc = (v >> 16) & 0xFF, d = v >> 24;
@@ -243,23 +283,43 @@ __global__ __launch_bounds__(TPB) void mj_k_idct_colour(MjDeviceBatch b) {
         }
         return;
     }
-    /* integer form of (uint32)(ratio * i), ratio = (float)sf / max_sf
-     * (colour_conversion.c:44-45, :62-69); exact for the factor pairs accepted */
-    const uint32_t h0 = im.comp[0].hsf, h1 = im.comp[1].hsf, h2 = im.comp[2].hsf;
-    const uint32_t v0 = im.comp[0].vsf, v1 = im.comp[1].vsf, v2 = im.comp[2].vsf;
-    const uint32_t hm = im.hmax, vm = im.vmax;
-    for (uint32_t i = threadIdx.x; i < quads * tile_h; i += TPB) {
-        const uint32_t y = i / quads, x = (i % quads) * 4;
-        const uint32_t gy = py0 + y, gx = px0 + x;
+    /* Source sample of output (i, j) in component c is (uint32)(ratio * i) with
+     * ratio = (float) sf_c / max_sf (colour_conversion.c:44-45, :62-69).  Sampling
+     * factors divide the maximum here, so that is i / (max_sf / sf_c): a shift when
+     * the quotient is 1, 2 or 4, a division by 3 otherwise. */
+    const uint32_t qh0 = im.hmax / im.comp[0].hsf, qh1 = im.hmax / im.comp[1].hsf, qh2 = im.hmax / im.comp[2].hsf;
+    const uint32_t qv0 = im.vmax / im.comp[0].vsf, qv1 = im.vmax / im.comp[1].vsf, qv2 = im.vmax / im.comp[2].vsf;
+    const bool pow2 = qh0 != 3 && qh1 != 3 && qh2 != 3 && qv0 != 3 && qv1 != 3 && qv2 != 3;
+    const uint32_t sh0 = qh0 >> 1, sh1 = qh1 >> 1, sh2 = qh2 >> 1;   /* 1,2,4 -> 0,1,2 */
+    const uint32_t sv0 = qv0 >> 1, sv1 = qv1 >> 1, sv2 = qv2 >> 1;
+    for (; y < tile_h; y += dy, qx += dq) {
+        if (qx >= quads) {
+            qx -= quads;
+            y++;
+            if (y >= tile_h) break;
+        }
+        const uint32_t x = qx * 4, gy = py0 + y, gx = px0 + x;
         if (gy >= im.Y || gx >= im.X) continue;
-        const uint8_t *r0 = s_plane + po0 + (y * v0 / vm) * pw0;
-        const uint8_t *r1 = s_plane + po1 + (y * v1 / vm) * pw1;
-        const uint8_t *r2 = s_plane + po2 + (y * v2 / vm) * pw2;
+        const uint8_t *r0, *r1, *r2;
         uint32_t px[4];
+        if (pow2) {
+            r0 = s_plane + po0 + (y >> sv0) * pw0;
+            r1 = s_plane + po1 + (y >> sv1) * pw1;
+            r2 = s_plane + po2 + (y >> sv2) * pw2;
 #pragma unroll
-        for (uint32_t k = 0; k < 4; k++) {
-            const uint32_t xx = x + k;
-            px[k] = ycc_to_rgb24(r0[xx * h0 / hm], r1[xx * h1 / hm], r2[xx * h2 / hm]);
+            for (uint32_t k = 0; k < 4; k++) {
+                const uint32_t xx = x + k;
+                px[k] = ycc_to_rgb24(r0[xx >> sh0], s_tcb[r1[xx >> sh1]], s_tcr[r2[xx >> sh2]]);
+            }
+        } else {
+            r0 = s_plane + po0 + (y / qv0) * pw0;
+            r1 = s_plane + po1 + (y / qv1) * pw1;
+            r2 = s_plane + po2 + (y / qv2) * pw2;
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {
+                const uint32_t xx = x + k;
+                px[k] = ycc_to_rgb24(r0[xx / qh0], s_tcb[r1[xx / qh1]], s_tcr[r2[xx / qh2]]);
+            }
         }
         uint8_t *o = rgb + (uint64_t) gy * im.pitch + 3 * gx;
         if (gx + 4 <= im.X) {
