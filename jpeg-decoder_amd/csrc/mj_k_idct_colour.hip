@@ -122,6 +122,86 @@ __device__ __forceinline__ uint32_t ycc_to_rgb24(uint32_t Y, const double2 tcb, 
     return store8(R) | (store8(G) << 8) | (store8(B) << 16);
 }
 
+/* 12-byte store of four RGB24 pixels (4-byte aligned) */
+struct __attribute__((aligned(4))) Rgb4 {
+    uint32_t a, b, c;
+};
+
+__device__ __forceinline__ void store_quad(uint8_t *o, const uint32_t px[4], uint32_t gx, uint32_t X) {
+    if (gx + 4 <= X) {
+        Rgb4 v;
+        v.a = px[0] | (px[1] << 24);
+        v.b = (px[1] >> 8) | (px[2] << 16);
+        v.c = (px[2] >> 16) | (px[3] << 8);
+        *reinterpret_cast<Rgb4 *>(o) = v;
+    } else {
+        for (uint32_t k = 0; k < 4 && gx + k < X; k++) {
+            o[3 * k] = (uint8_t) px[k];
+            o[3 * k + 1] = (uint8_t) (px[k] >> 8);
+            o[3 * k + 2] = (uint8_t) (px[k] >> 16);
+        }
+    }
+}
+
+/*
+ * Colour stage for the common layouts: luma at full resolution, both chroma
+ * components subsampled by 2^SH horizontally and 2^SV vertically (4:4:4, 4:2:2,
+ * 4:2:0, 4:4:0, 4:1:1).  A thread converts a patch of 4 x 2^SV pixels per step, so
+ * every chroma sample and its two table rows are fetched once per patch.
+ */
+template <int SH, int SV>
+__device__ __forceinline__ void colour_fast(const uint8_t *s_plane, const double2 *s_tcb, const double2 *s_tcr,
+                                            uint32_t po1, uint32_t po2, uint32_t pw0, uint32_t pwc, uint32_t tile_w,
+                                            uint32_t tile_h, uint32_t px0, uint32_t py0, uint32_t X, uint32_t Y,
+                                            uint32_t pitch, uint8_t *rgb) {
+    constexpr int NC = 4 >> SH, ROWS = 1 << SV;
+    const uint32_t quads = tile_w / 4, prow_n = tile_h >> SV;
+    const uint32_t dy = TPB / quads, dq = TPB - dy * quads;
+    uint32_t pr = threadIdx.x / quads;
+    uint32_t qx = threadIdx.x - pr * quads;
+    for (; pr < prow_n; pr += dy, qx += dq) {
+        if (qx >= quads) {
+            qx -= quads;
+            pr++;
+            if (pr >= prow_n) break;
+        }
+        const uint32_t x = qx * 4, gx = px0 + x;
+        const uint32_t y = pr << SV, gy = py0 + y;
+        if (gy >= Y || gx >= X) continue;
+        /* chroma samples of the patch and their product rows */
+        const uint8_t *cbp = s_plane + po1 + pr * pwc + (x >> SH);
+        const uint8_t *crp = s_plane + po2 + pr * pwc + (x >> SH);
+        uint32_t cbw, crw;
+        if (SH == 0) {
+            cbw = *reinterpret_cast<const uint32_t *>(cbp);
+            crw = *reinterpret_cast<const uint32_t *>(crp);
+        } else if (SH == 1) {
+            cbw = *reinterpret_cast<const uint16_t *>(cbp);
+            crw = *reinterpret_cast<const uint16_t *>(crp);
+        } else {
+            cbw = *cbp;
+            crw = *crp;
+        }
+        double2 tb[NC], tr[NC];
+#pragma unroll
+        for (int i = 0; i < NC; i++) {
+            tb[i] = s_tcb[(cbw >> (8 * i)) & 0xFFu];
+            tr[i] = s_tcr[(crw >> (8 * i)) & 0xFFu];
+        }
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) {
+            if (gy + r >= Y) break;
+            const uint32_t yw = *reinterpret_cast<const uint32_t *>(s_plane + (y + r) * pw0 + x);
+            uint32_t px[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                px[k] = ycc_to_rgb24((yw >> (8 * k)) & 0xFFu, tb[k >> SH], tr[k >> SH]);
+            }
+            store_quad(rgb + (uint64_t) (gy + r) * pitch + 3 * gx, px, gx, X);
+        }
+    }
+}
+
 #ifndef MJ_IDCT_WAVES
 #define MJ_IDCT_WAVES 3
 #endif
@@ -283,6 +363,27 @@ __global__ __launch_bounds__(TPB, MJ_IDCT_WAVES) void mj_k_idct_colour(MjDeviceB
         }
         return;
     }
+    {
+        const uint32_t ch = im.hmax / im.comp[1].hsf, cv = im.vmax / im.comp[1].vsf;
+        const bool same = im.comp[1].hsf == im.comp[2].hsf && im.comp[1].vsf == im.comp[2].vsf &&
+                          im.comp[0].hsf == im.hmax && im.comp[0].vsf == im.vmax;
+        if (same && ch != 3 && cv <= 2) {
+            const uint32_t pwc = pw1;
+#define MJ_FAST(SH, SV)                                                                                          \
+    colour_fast<SH, SV>(s_plane, s_tcb, s_tcr, po1, po2, pw0, pwc, tile_w, tile_h, px0, py0, im.X, im.Y, im.pitch, rgb)
+            if (cv == 1) {
+                if (ch == 1) MJ_FAST(0, 0);
+                else if (ch == 2) MJ_FAST(1, 0);
+                else MJ_FAST(2, 0);
+            } else {
+                if (ch == 1) MJ_FAST(0, 1);
+                else if (ch == 2) MJ_FAST(1, 1);
+                else MJ_FAST(2, 1);
+            }
+#undef MJ_FAST
+            return;
+        }
+    }
     /* Source sample of output (i, j) in component c is (uint32)(ratio * i) with
      * ratio = (float) sf_c / max_sf (colour_conversion.c:44-45, :62-69).  Sampling
      * factors divide the maximum here, so that is i / (max_sf / sf_c): a shift when
@@ -321,19 +422,7 @@ __global__ __launch_bounds__(TPB, MJ_IDCT_WAVES) void mj_k_idct_colour(MjDeviceB
                 px[k] = ycc_to_rgb24(r0[xx / qh0], s_tcb[r1[xx / qh1]], s_tcr[r2[xx / qh2]]);
             }
         }
-        uint8_t *o = rgb + (uint64_t) gy * im.pitch + 3 * gx;
-        if (gx + 4 <= im.X) {
-            uint32_t *o32 = reinterpret_cast<uint32_t *>(o);
-            o32[0] = px[0] | (px[1] << 24);
-            o32[1] = (px[1] >> 8) | (px[2] << 16);
-            o32[2] = (px[2] >> 16) | (px[3] << 8);
-        } else {
-            for (uint32_t k = 0; k < 4 && gx + k < im.X; k++) {
-                o[3 * k] = (uint8_t) px[k];
-                o[3 * k + 1] = (uint8_t) (px[k] >> 8);
-                o[3 * k + 2] = (uint8_t) (px[k] >> 16);
-            }
-        }
+        store_quad(rgb + (uint64_t) gy * im.pitch + 3 * gx, px, gx, im.X);
     }
 }
 
