@@ -18,20 +18,34 @@
 #define MJ_STREAM_PAD 64       /* readable zero bytes after every compacted stream */
 #define MJ_NO_TERMINATOR 0xFFFFFFFFu
 
+#define MJ_SUB_BITS (16 - MJ_LUT_BITS)
+#define MJ_SUB_SIZE (1 << MJ_SUB_BITS)
+#define MJ_SUB_MAX 8           /* second-level tables per Huffman table */
+#define MJ_LUT_LONG 0xF000u    /* first-level entry: code longer than MJ_LUT_BITS, low byte = second-level table */
+#define MJ_LUT_WALK 0xE000u    /* first-level entry: longer code that found no second-level table: canonical walk */
+
 /* One Huffman table, flattened from the reference's HuffTable (huff_table.h:9-14):
- * a direct lookup on the next MJ_LUT_BITS bits for short codes, and the canonical
- * ranges (decode.c:674-681 compares against max_codes per length) for longer ones. */
+ * a direct lookup on the next MJ_LUT_BITS bits for short codes; for longer codes a
+ * second-level lookup on the following MJ_SUB_BITS bits, selected by the first-level
+ * entry; and the canonical ranges (decode.c:674-681 compares against max_codes per
+ * length) as the fallback for tables that need more second-level tables than fit. */
 typedef struct {
-    uint16_t lut[MJ_LUT_SIZE]; /* (length << 8) | symbol, 0 = code longer than MJ_LUT_BITS or invalid */
+    uint16_t lut[MJ_LUT_SIZE]; /* (length << 8) | symbol; MJ_LUT_LONG | n; MJ_LUT_WALK; 0 = no code has this prefix */
+    uint16_t sub[MJ_SUB_MAX][MJ_SUB_SIZE]; /* (length << 8) | symbol, 0 = no such code */
+} MjHuffDev;                   /* the part the kernels keep in LDS */
+
+typedef struct {
     int32_t maxcode[17];       /* [len] last code of that length (right-justified), -1 if none */
     int32_t valoff[17];        /* [len] index into vals of code 0 of that length: valptr - mincode */
     uint8_t vals[256];
-} MjHuffDev;
+    uint32_t pad_[2];
+} MjHuffWalk;                  /* canonical ranges, read from HBM only on MJ_LUT_WALK entries */
 
 typedef struct {
     uint32_t ntab;
     uint32_t pad_[3];
     MjHuffDev tab[MJ_MAX_TABS];
+    MjHuffWalk walk[MJ_MAX_TABS];
 } MjHuffSet;
 
 typedef struct {

@@ -59,7 +59,7 @@ struct Rec {
 
 Rec span(const MjScanCtx &cx, uint32_t p, uint32_t k, uint32_t c, uint32_t end) {
     Rec r{p, k, c, 0, {0, 0, 0, 0}};
-    mj_decode_span<false>(cx, r.p, r.k, r.c, end, r.nb, r.d[0], r.d[1], r.d[2], r.d[3], 0, 0);
+    mj_decode_span(cx, r.p, r.k, r.c, end, r.nb, r.d, 1);
     return r;
 }
 
@@ -110,12 +110,14 @@ int64_t mj_emu_decode_coefs(const uint8_t *file, size_t len, int16_t *coefs, int
 
     MjScanCtx cx;
     cx.stream = (const uint32_t *) L.cmp.data();
-    cx.tabs = set->tab;
+    uint32_t slots[MJ_MAX_BPM + 2];
+    for (uint32_t i = 0; i < img.bpm; i++) slots[i] = mj_slot_pack(img.blk_comp[i], img.blk_dc[i], img.blk_ac[i]);
+    cx.tabs = (const unsigned char *) set->tab;
+    cx.walk = set->walk;
+    cx.slots = slots;
     cx.coefs = coefs;
     cx.bpm = img.bpm;
-    cx.dc_sel = mj_pack_sel(img.blk_dc, img.bpm);
-    cx.ac_sel = mj_pack_sel(img.blk_ac, img.bpm);
-    cx.comp_sel = mj_pack_sel(img.blk_comp, img.bpm);
+    cx.wi_mask = 0xFFFFFFFFu;
 
     int64_t st_subs = 0, st_rounds = 0, st_maxr = 0, st_seqs = 0, st_multi = 0, st_fix = 0;
 
@@ -217,12 +219,12 @@ int64_t mj_emu_decode_coefs(const uint8_t *file, size_t len, int16_t *coefs, int
             memset(buf, 0, sizeof buf);
             const uint32_t end = sub_end(j);
             if (mj_write_live(p, k, skip, end, b1)) {
-                MjBits bw;
-                mj_bits_init(bw, cx.stream, p);
-                while (mj_write_live(p, k, skip, end, b1)) {
+                MjLane L;
+                mj_lane_init(cx, L, p, k, c);
+                while (mj_write_live(L.p, L.k, skip, end, b1)) {
                     bool fin = false;
                     uint32_t fin_blk = 0;
-                    mj_write_step(cx, bw, p, k, c, skip, blk, blk_end, d[0], d[1], d[2], d[3], buf, fin, fin_blk);
+                    mj_write_step(cx, L, skip, blk, blk_end, d, 1, buf, fin, fin_blk);
                     if (fin) {
                         memcpy(coefs + (size_t) fin_blk * 64, buf, sizeof buf);
                         memset(buf, 0, sizeof buf);

@@ -4,7 +4,11 @@
  * the CPU tests.  mj_step() decodes one symbol; it is what decode_data_unit()
  * (decode.c:665-723) plus the bit reader (bitstream.c:61-78) do per symbol,
  * restated over an unstuffed, marker-free stream and restartable at any symbol
- * boundary.  mj_decode_span() runs it from a given state up to a bit position.
+ * boundary.
+ *
+ * The code is written for the GPU's instruction budget: every lane of a wavefront
+ * executes every "rare" branch that any lane takes, so the per-symbol path is
+ * branch-light, 32-bit only, and keeps per-block work (table selection) out of it.
  */
 #ifndef MJ_ENTROPY_CORE_H
 #define MJ_ENTROPY_CORE_H
@@ -20,163 +24,247 @@
 #define MJ_HD static inline
 #endif
 
+/* Per block slot of the MCU: LDS/host byte offsets of its DC and AC tables and its
+ * component, packed: bits 0-1 component, bits 2-15 DC table offset / 4, bits 16-31
+ * AC table offset / 4 (tables are 16-byte multiples). */
+MJ_HD uint32_t mj_slot_pack(uint32_t comp, uint32_t tdc, uint32_t tac) {
+    return (comp & 3u) | ((tdc * (uint32_t) (sizeof(MjHuffDev) / 4)) << 2) | ((tac * (uint32_t) (sizeof(MjHuffDev) / 4)) << 16);
+}
+
 /* Wave-uniform description of the scan a lane is decoding. */
 struct MjScanCtx {
-    const uint32_t *stream;   /* the image's compacted stream as big-endian 32-bit words */
-    const MjHuffDev *tabs;    /* the image's Huffman tables (LDS on the device) */
-    int16_t *coefs;           /* block 0 of the image; 64 int16 per block, zigzag order */
-    uint32_t bpm;             /* blocks per MCU */
-    uint64_t dc_sel, ac_sel;  /* 4 bits per block slot: table index for DC / AC symbols */
-    uint64_t comp_sel;        /* 4 bits per block slot: component */
+    const uint32_t *stream;      /* the image's compacted stream, 32-bit words in file byte order; 16-byte aligned on the device */
+    const unsigned char *tabs;   /* the image's MjHuffDev array (LDS on the device) */
+    const MjHuffWalk *walk;      /* the matching canonical ranges (HBM on the device) */
+    const uint32_t *slots;       /* [bpm] mj_slot_pack() per block slot (LDS on the device) */
+    int16_t *coefs;              /* block 0 of the image; 64 int16 per block, zigzag order */
+    uint32_t bpm;                /* blocks per MCU */
+    uint32_t wi_mask;            /* 0xFFFFFFFF; timing experiments narrow it so every lane reads the same few blocks */
 };
 
 MJ_HD uint32_t mj_be32(uint32_t v) {
     return __builtin_bswap32(v);
 }
 
-MJ_HD uint64_t mj_pack_sel(const uint8_t *v, uint32_t n) {
-    uint64_t r = 0;
-    for (uint32_t i = 0; i < n; i++) {
-        r |= (uint64_t) (v[i] & 15u) << (4 * i);
-    }
-    return r;
+/* (hi:lo) >> sh, low 32 bits, for 1 <= sh <= 31 (v_alignbit_b32 on the device) */
+MJ_HD uint32_t mj_align(uint32_t hi, uint32_t lo, uint32_t sh) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(hi, lo, sh);
+#else
+    return (uint32_t) ((((uint64_t) hi << 32) | lo) >> sh);
+#endif
 }
 
-/* Bit window over the stream: the next `avail` (>= 33 after a refill) bits are the
- * top bits of buf.  nxt_raw is the following word, loaded one refill ahead and left
- * byte-swapped-later so that the load's latency overlaps several symbols. */
-struct MjBits {
-    uint64_t buf;
-    int32_t avail;
-    uint32_t wi;
-    uint32_t nxt_raw;
+/* Four consecutive stream words (one 16-byte load per lane: scattered per-lane
+ * dword loads cost one cache-line access each and saturate the vector memory path
+ * long before the ALUs; 16 bytes per access cuts those accesses four-fold). */
+struct MjQuad {
+    uint32_t w0, w1, w2, w3;
 };
 
-MJ_HD void mj_bits_init(MjBits &bw, const uint32_t *stream, uint32_t p) {
-    uint32_t wi = p >> 5;
-    bw.buf = (((uint64_t) mj_be32(stream[wi]) << 32) | mj_be32(stream[wi + 1])) << (p & 31);
-    bw.avail = 64 - (int32_t) (p & 31);
-    bw.wi = wi + 2;
-    bw.nxt_raw = stream[bw.wi];
+MJ_HD MjQuad mj_load_quad(const MjScanCtx &cx, uint32_t block) {
+    MjQuad q;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint4 v = reinterpret_cast<const uint4 *>(cx.stream)[block & cx.wi_mask];
+    q.w0 = v.x;
+    q.w1 = v.y;
+    q.w2 = v.z;
+    q.w3 = v.w;
+#else
+    const uint32_t *s = cx.stream + 4u * (size_t) (block & cx.wi_mask);
+    q.w0 = s[0];
+    q.w1 = s[1];
+    q.w2 = s[2];
+    q.w3 = s[3];
+#endif
+    return q;
 }
 
-MJ_HD void mj_bits_refill(MjBits &bw, const uint32_t *stream) {
-    if (bw.avail <= 32) {
-        bw.buf |= (uint64_t) mj_be32(bw.nxt_raw) << (32 - bw.avail);
-        bw.avail += 32;
-        bw.wi++;
-        bw.nxt_raw = stream[bw.wi];
+/* Decoder state of one lane.  (p, k, c) is the state proper -- equal (p, k, c)
+ * decode identically from there on; the rest is derived from it. */
+struct MjLane {
+    uint32_t hi, lo;    /* next `avail` stream bits, left-aligned in hi:lo, zero below */
+    int32_t avail;      /* > 32 after mj_refill */
+    MjQuad cur;         /* words not yet in the window; cur.w0 is the next one */
+    uint32_t ncur;      /* how many of them are left (1..4) */
+    MjQuad nxt;         /* the following 16 bytes, requested one block ahead */
+    uint32_t blk16;     /* index of the 16-byte block held in nxt */
+    uint32_t p;         /* bit offset of the next symbol */
+    uint32_t k;         /* zigzag index of the next coefficient; 0: the DC symbol comes next */
+    uint32_t c;         /* block slot inside the MCU */
+    uint32_t slot;      /* cx.slots[c] */
+    uint32_t slot_nx;   /* cx.slots[next c]: fetched a block ahead so the lookup is off the critical path */
+};
+
+/* next stream word, byte-swapped to bit order */
+MJ_HD uint32_t mj_take_word(const MjScanCtx &cx, MjLane &L) {
+    const uint32_t w = mj_be32(L.cur.w0);
+    L.cur.w0 = L.cur.w1;
+    L.cur.w1 = L.cur.w2;
+    L.cur.w2 = L.cur.w3;
+    if (--L.ncur == 0) {
+        L.cur = L.nxt;
+        L.ncur = 4;
+        L.blk16++;
+        L.nxt = mj_load_quad(cx, L.blk16);   /* not touched for another four words */
+    }
+    return w;
+}
+
+MJ_HD void mj_lane_init(const MjScanCtx &cx, MjLane &L, uint32_t p, uint32_t k, uint32_t c) {
+    const uint32_t wi = p >> 5, sh = p & 31u;
+    L.blk16 = wi >> 2;
+    L.cur = mj_load_quad(cx, L.blk16);
+    L.blk16++;
+    L.nxt = mj_load_quad(cx, L.blk16);
+    L.ncur = 4;
+    for (uint32_t i = wi & 3u; i != 0; i--) {
+        (void) mj_take_word(cx, L);
+    }
+    const uint32_t w0 = mj_take_word(cx, L), w1 = mj_take_word(cx, L);
+    L.hi = sh ? mj_align(w0, w1, 32u - sh) : w0;
+    L.lo = w1 << sh;
+    L.avail = 64 - (int32_t) sh;
+    L.p = p;
+    L.k = k;
+    L.c = c;
+    L.slot = cx.slots[c];
+    L.slot_nx = cx.slots[(c + 1 == cx.bpm) ? 0 : c + 1];
+}
+
+/* Top the window up to more than 32 bits. */
+MJ_HD void mj_refill(const MjScanCtx &cx, MjLane &L) {
+    if (L.avail <= 32) {
+        const uint32_t w = mj_take_word(cx, L);
+        L.hi |= (w >> 1) >> (L.avail - 1);         /* avail in [1, 32] */
+        L.lo = w << (32 - L.avail);
+        L.avail += 32;
     }
 }
 
 /* What one symbol did. */
 struct MjSym {
-    int32_t val;      /* DC difference, or AC coefficient value */
+    int32_t val;      /* DC difference, or AC coefficient value (0 when VAL is off for AC) */
     uint32_t kpos;    /* zigzag position the value belongs to (0 for DC) */
-    uint32_t comp;    /* component, valid when dc */
+    uint32_t comp;    /* component of the block the symbol belongs to */
     bool dc;          /* the symbol was the block's DC */
     bool store;       /* val is a coefficient to store (DC always; AC when size != 0 and in range) */
     bool done;        /* the block ended with this symbol */
 };
 
 /*
- * Decode one symbol at state (p, k, c) and advance the state.
- *   p  bit offset in the stream; k  zigzag index of the next coefficient (0: the
- *   block's DC symbol comes next); c  block slot inside the MCU.
- * The caller has refilled bw (mj_bits_refill) since the previous step.
+ * Decode one symbol and advance the lane.  The caller has run mj_refill since the
+ * previous step.  AC_VAL: also produce the value of AC coefficients (the writing
+ * pass needs it, the synchronisation passes only need the bit count).
  */
-MJ_HD MjSym mj_step(const MjScanCtx &cx, MjBits &bw, uint32_t &p, uint32_t &k, uint32_t &c) {
+template <bool AC_VAL>
+MJ_HD MjSym mj_step(const MjScanCtx &cx, MjLane &L) {
     MjSym s;
-    const bool isac = (k != 0);
-    const uint32_t t = (uint32_t) ((isac ? cx.ac_sel : cx.dc_sel) >> (4 * c)) & 15u;
-    const MjHuffDev *T = cx.tabs + t;
-    const uint32_t w = (uint32_t) (bw.buf >> 48);
-    const uint32_t e = T->lut[w >> (16 - MJ_LUT_BITS)];
+    const bool isac = (L.k != 0);
+    const uint32_t toff = (isac ? (L.slot >> 16) : ((L.slot >> 2) & 0x3FFFu)) * 4u;
+    const unsigned char *T = cx.tabs + toff;
+    const uint32_t e = *reinterpret_cast<const uint16_t *>(T + ((L.hi >> (32 - MJ_LUT_BITS)) << 1));
     uint32_t len = e >> 8, sym = e & 255u;
-    if (len == 0) {
-        /* code longer than the direct table: canonical ranges per length
-         * (the reference compares against max_codes per length, decode.c:674-681) */
+    if (len - 1u >= 16u) {
+        /* not a short code: second-level table, canonical walk, or no code at all */
+        const MjHuffDev *H = reinterpret_cast<const MjHuffDev *>(T);
+        const MjHuffWalk *W = cx.walk + toff / (uint32_t) sizeof(MjHuffDev);
+        const uint32_t w = L.hi >> 16;
+        const uint32_t kind = e & 0xFF00u;
         len = 16;
-        sym = 0;
-        for (uint32_t L = MJ_LUT_BITS + 1; L <= 16; L++) {
-            const int32_t code = (int32_t) (w >> (16 - L));
-            if (code <= T->maxcode[L]) {
-                sym = T->vals[(uint32_t) (T->valoff[L] + code) & 255u];
-                len = L;
-                break;
+        sym = 0;   /* no such code: 16 bits are consumed as an end-of-block */
+        if (kind == MJ_LUT_LONG) {
+            /* the MJ_SUB_BITS bits after the first MJ_LUT_BITS index the second level */
+            const uint32_t e2 = H->sub[e & (MJ_SUB_MAX - 1)][w & (MJ_SUB_SIZE - 1)];
+            if (e2) {
+                len = e2 >> 8;
+                sym = e2 & 255u;
+            }
+        } else if (kind == MJ_LUT_WALK) {
+            /* canonical ranges per length (the reference's own walk, decode.c:674-681) */
+            for (uint32_t l = MJ_LUT_BITS + 1; l <= 16; l++) {
+                const int32_t code = (int32_t) (w >> (16 - l));
+                if (code <= W->maxcode[l]) {
+                    sym = W->vals[(uint32_t) (W->valoff[l] + code) & 255u];
+                    len = l;
+                    break;
+                }
             }
         }
     }
     const uint32_t size = sym & 15u;
-    const uint32_t rest = (uint32_t) ((bw.buf << len) >> 32);
-    const uint32_t mag = size ? (rest >> (32 - size)) : 0u;
-    /* EXTEND (decode.c:684-686, :716-718) */
-    s.val = (size && mag < (1u << (size - 1))) ? (int32_t) mag - (int32_t) (1u << size) + 1 : (int32_t) mag;
-    const uint32_t used = len + size;
-    bw.buf <<= used;
-    bw.avail -= (int32_t) used;
-    p += used;
+    const uint32_t used = len + size;          /* 1..31 */
     s.dc = !isac;
-    s.comp = (uint32_t) (cx.comp_sel >> (4 * c)) & 15u;
+    s.comp = L.slot & 3u;
+    s.val = 0;
+    if (AC_VAL || !isac) {
+        /* the `size` bits after the code, then EXTEND (decode.c:684-686, :716-718):
+         * a leading 1 means the value as read, a leading 0 means value - 2^size + 1 */
+        const uint32_t rest = mj_align(L.hi, L.lo, 32u - len);
+        const uint32_t neg = (uint32_t) ((int32_t) ~rest >> 31);       /* all ones when the leading bit is 0 */
+        const uint32_t mag = ((rest ^ neg) >> 1) >> (31u - size);      /* size 0 -> 0 */
+        s.val = (int32_t) ((mag ^ neg) - neg);
+    }
+    L.hi = mj_align(L.hi, L.lo, 32u - used);
+    L.lo <<= used;
+    L.avail -= (int32_t) used;
+    L.p += used;
     if (!isac) {
         s.kpos = 0;
         s.store = true;
-        k = 1;
-    } else if (sym == 0) {
-        s.kpos = 0;
-        s.store = false;
-        k = 64; /* EOB */
+        L.k = 1;
     } else {
-        k += sym >> 4; /* run; ZRL (0xF0) has size 0 and nets +16 */
-        s.kpos = k;
-        s.store = (size != 0) && (k < 64);
-        k += 1;
+        const uint32_t kk = L.k + (sym >> 4);  /* run; ZRL (0xF0) has size 0 and nets +16 */
+        s.kpos = kk;
+        s.store = (size != 0) && (kk < 64);
+        L.k = (sym == 0) ? 64u : kk + 1;       /* 0x00 = end of block */
     }
-    s.done = (k >= 64);
+    s.done = (L.k >= 64);
     if (s.done) {
-        k = 0;
-        c = (c + 1 == cx.bpm) ? 0 : c + 1;
+        L.k = 0;
+        L.c = (L.c + 1 == cx.bpm) ? 0 : L.c + 1;
+        L.slot = L.slot_nx;
+        L.slot_nx = cx.slots[(L.c + 1 == cx.bpm) ? 0 : L.c + 1];
     }
     return s;
 }
 
+/* Per-component DC accumulators (decode.c:682-690; the int16 wrap is applied when a
+ * value is stored): lane-private words acc[comp * stride], in LDS on the device so
+ * that the component index costs one address computation instead of a select per
+ * component.  Returns the updated accumulator. */
+MJ_HD int32_t mj_dc_add(int32_t *acc, uint32_t stride, uint32_t comp, int32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __hip_atomic_fetch_add(acc + comp * stride, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) + v;
+#else
+    acc[comp * stride] += v;
+    return acc[comp * stride];
+#endif
+}
+
 /*
- * Decode symbols from state (p, k, c) until p >= end.  nb is advanced by the number
- * of blocks completed.  d0..d3 are per-component DC accumulators: every DC
- * difference is added to its component's accumulator (decode.c:682-690; the int16
- * wrap is applied when the value is stored).  With WRITE, coefficients are stored
- * straight to cx.coefs for blocks blk <= index < blk_end, where blk is the block the
- * entry state is in; the caller supplies zero-filled blocks (decode.c:612) and the
- * accumulators must hold the predictors on entry.
+ * Decode symbols from state (p, k, c) until p >= end, counting only: nb is advanced
+ * by the number of blocks completed and every DC difference is added to its
+ * component's accumulator.
  */
-template <bool WRITE>
 MJ_HD void mj_decode_span(const MjScanCtx &cx, uint32_t &p, uint32_t &k, uint32_t &c, uint32_t end, uint32_t &nb,
-                          int32_t &d0, int32_t &d1, int32_t &d2, int32_t &d3, uint32_t blk, uint32_t blk_end) {
+                          int32_t *acc, uint32_t stride) {
     if (p >= end) {
         return;
     }
-    MjBits bw;
-    mj_bits_init(bw, cx.stream, p);
-    while (p < end) {
-        mj_bits_refill(bw, cx.stream);
-        const MjSym s = mj_step(cx, bw, p, k, c);
+    MjLane L;
+    mj_lane_init(cx, L, p, k, c);
+    while (L.p < end) {
+        mj_refill(cx, L);
+        const MjSym s = mj_step<false>(cx, L);
         if (s.dc) {
-            d0 += (s.comp == 0) ? s.val : 0;
-            d1 += (s.comp == 1) ? s.val : 0;
-            d2 += (s.comp == 2) ? s.val : 0;
-            d3 += (s.comp == 3) ? s.val : 0;
-            if (WRITE && blk < blk_end) {
-                const int32_t dc = (s.comp == 0) ? d0 : (s.comp == 1) ? d1 : (s.comp == 2) ? d2 : d3;
-                cx.coefs[(uint64_t) blk * 64] = (int16_t) dc;
-            }
-        } else if (WRITE && s.store && blk < blk_end) {
-            cx.coefs[(uint64_t) blk * 64 + s.kpos] = (int16_t) s.val;
+            (void) mj_dc_add(acc, stride, s.comp, s.val);
         }
-        if (s.done) {
-            nb++;
-            blk++;
-        }
+        nb += s.done ? 1u : 0u;
     }
+    p = L.p;
+    k = L.k;
+    c = L.c;
 }
 
 /*
@@ -188,25 +276,19 @@ MJ_HD void mj_decode_span(const MjScanCtx &cx, uint32_t &p, uint32_t &k, uint32_
  * entry state is in the middle of a block (k != 0) runs in `skip` mode until that
  * block ends -- the previous lane finishes it by decoding past its own subsequence
  * end (see mj_write_live) -- so every block is assembled by exactly one lane and
- * leaves the chip as one full 128-byte line.
+ * leaves the chip as one full 128-byte line.  acc holds the DC predictors.
  */
-MJ_HD void mj_write_step(const MjScanCtx &cx, MjBits &bw, uint32_t &p, uint32_t &k, uint32_t &c, bool &skip,
-                         uint32_t &blk, uint32_t blk_end, int32_t &d0, int32_t &d1, int32_t &d2, int32_t &d3,
-                         int16_t *blkbuf, bool &fin, uint32_t &fin_blk) {
-    mj_bits_refill(bw, cx.stream);
-    const MjSym s = mj_step(cx, bw, p, k, c);
+MJ_HD void mj_write_step(const MjScanCtx &cx, MjLane &L, bool &skip, uint32_t &blk, uint32_t blk_end, int32_t *acc,
+                         uint32_t stride, int16_t *blkbuf, bool &fin, uint32_t &fin_blk) {
+    mj_refill(cx, L);
+    const MjSym s = mj_step<true>(cx, L);
     const bool mine = !skip && blk < blk_end;
+    int32_t v = s.val;
     if (s.dc) {
-        d0 += (s.comp == 0) ? s.val : 0;
-        d1 += (s.comp == 1) ? s.val : 0;
-        d2 += (s.comp == 2) ? s.val : 0;
-        d3 += (s.comp == 3) ? s.val : 0;
-        if (mine) {
-            const int32_t dc = (s.comp == 0) ? d0 : (s.comp == 1) ? d1 : (s.comp == 2) ? d2 : d3;
-            blkbuf[0] = (int16_t) dc;
-        }
-    } else if (s.store && mine) {
-        blkbuf[s.kpos] = (int16_t) s.val;
+        v = mj_dc_add(acc, stride, s.comp, s.val);
+    }
+    if (s.store && mine) {
+        blkbuf[s.kpos] = (int16_t) v;
     }
     fin = false;
     if (s.done) {

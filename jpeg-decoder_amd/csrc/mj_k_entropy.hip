@@ -66,23 +66,41 @@ __device__ __forceinline__ uint32_t sub_end(const Geo &g, uint32_t j, uint32_t S
 
 extern __shared__ __align__(16) unsigned char s_dyn[];
 
-/* cooperative copy of the image's Huffman tables into LDS */
-__device__ __forceinline__ void load_tables(MjHuffDev *s_tabs, const MjHuffSet &set) {
-    const uint32_t n = set.ntab * (uint32_t) (sizeof(MjHuffDev) / 4);
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(set.tab);
-    uint32_t *dst = reinterpret_cast<uint32_t *>(s_tabs);
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+/* LDS carve-up shared by all entropy kernels: [Huffman tables][16 slot words]... */
+__device__ __forceinline__ uint32_t *lds_slots(const MjDeviceBatch &b) {
+    return reinterpret_cast<uint32_t *>(s_dyn + b.max_ntab * sizeof(MjHuffDev));
+}
+/* per-lane DC accumulators: [wave][component][lane] */
+__device__ __forceinline__ int32_t *lds_dc(const MjDeviceBatch &b) {
+    return reinterpret_cast<int32_t *>(s_dyn + b.max_ntab * sizeof(MjHuffDev) + 16 * sizeof(uint32_t));
+}
+constexpr uint32_t DC_LDS_BYTES = 4u * 64u * MJ_MAX_COMP * sizeof(int32_t);   /* up to 4 waves */
+__device__ __forceinline__ unsigned char *lds_after_dc(const MjDeviceBatch &b) {
+    return reinterpret_cast<unsigned char *>(lds_dc(b)) + DC_LDS_BYTES;
 }
 
-__device__ __forceinline__ MjScanCtx make_ctx(const MjDeviceBatch &b, const MjImageDev &im, const MjHuffDev *s_tabs) {
+/* cooperative copy of the image's Huffman tables and per-slot table selection into
+ * LDS (the caller synchronises) */
+__device__ __forceinline__ void load_tables(const MjDeviceBatch &b, const MjImageDev &im) {
+    const MjHuffSet &set = b.sets[im.huff_set];
+    const uint32_t n = set.ntab * (uint32_t) (sizeof(MjHuffDev) / 4);
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(set.tab);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(s_dyn);
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+    if (threadIdx.x < im.bpm) {
+        lds_slots(b)[threadIdx.x] = mj_slot_pack(im.blk_comp[threadIdx.x], im.blk_dc[threadIdx.x], im.blk_ac[threadIdx.x]);
+    }
+}
+
+__device__ __forceinline__ MjScanCtx make_ctx(const MjDeviceBatch &b, const MjImageDev &im) {
     MjScanCtx cx;
     cx.stream = reinterpret_cast<const uint32_t *>(b.cmp + im.cmp_off);
-    cx.tabs = s_tabs;
+    cx.tabs = s_dyn;
+    cx.walk = b.sets[im.huff_set].walk;
+    cx.slots = lds_slots(b);
     cx.coefs = b.coefs + im.coef_off * 64;
     cx.bpm = im.bpm;
-    cx.dc_sel = mj_pack_sel(im.blk_dc, im.bpm);
-    cx.ac_sel = mj_pack_sel(im.blk_ac, im.bpm);
-    cx.comp_sel = mj_pack_sel(im.blk_comp, im.bpm);
+    cx.wi_mask = (b.dbg & 32u) ? 15u : 0xFFFFFFFFu;
     return cx;
 }
 
@@ -91,18 +109,22 @@ struct LaneRec {      /* what a lane knows about one subsequence */
     int32_t d0, d1, d2, d3;
 };
 
-__device__ __forceinline__ LaneRec decode_nowrite(const MjScanCtx &cx, uint32_t p, uint32_t kc, uint32_t end) {
+/* acc: this lane's accumulators, acc[comp * 64] */
+__device__ __forceinline__ LaneRec decode_nowrite(const MjScanCtx &cx, uint32_t p, uint32_t kc, uint32_t end, int32_t *acc) {
     uint32_t k = kc & 0xFFu, c = kc >> 8, nb = 0;
-    int32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0;
-    mj_decode_span<false>(cx, p, k, c, end, nb, d0, d1, d2, d3, 0, 0);
+    acc[0] = 0;
+    acc[64] = 0;
+    acc[128] = 0;
+    acc[192] = 0;
+    mj_decode_span(cx, p, k, c, end, nb, acc, 64);
     LaneRec r;
     r.p = p;
     r.kc = (c << 8) | k;
     r.nb = nb;
-    r.d0 = d0;
-    r.d1 = d1;
-    r.d2 = d2;
-    r.d3 = d3;
+    r.d0 = acc[0];
+    r.d1 = acc[64];
+    r.d2 = acc[128];
+    r.d3 = acc[192];
     return r;
 }
 
@@ -142,25 +164,17 @@ __device__ __forceinline__ void wave_excl_scan5(uint32_t &nb, int32_t &d0, int32
     d3 = i3 - d3;
 }
 
-/* The writing pass of one lane: decode its subsequence from the exact entry state. */
-__device__ __forceinline__ void write_pass(const MjScanCtx &cx, uint32_t p, uint32_t kc, uint32_t end, uint32_t blk,
-                                           uint32_t blk_end, int32_t d0, int32_t d1, int32_t d2, int32_t d3) {
-    uint32_t k = kc & 0xFFu, c = kc >> 8, nb = 0;
-    mj_decode_span<true>(cx, p, k, c, end, nb, d0, d1, d2, d3, blk, blk_end);
-}
-
 /* ------------------------------------------------------------------------ */
 /* kernel 1: per sequence -- cold decode, lock-step synchronisation rounds, */
 /* and, for single-sequence intervals, prefix sums + the writing pass       */
 /* ------------------------------------------------------------------------ */
 __global__ __launch_bounds__(TPB) void mj_k_entropy_sync(MjDeviceBatch b) {
-    MjHuffDev *s_tabs = reinterpret_cast<MjHuffDev *>(s_dyn);
     const uint32_t ii = b.wg_img[blockIdx.x];
     const MjImageDev &im = b.img[ii];
     const uint32_t n_seq = b.dyn[ii].n_seq;
     const uint32_t seq0 = (blockIdx.x - im.wg_first) * WAVES;
     if (seq0 >= n_seq) return;
-    load_tables(s_tabs, b.sets[im.huff_set]);
+    load_tables(b, im);
     __syncthreads();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
@@ -172,7 +186,7 @@ __global__ __launch_bounds__(TPB) void mj_k_entropy_sync(MjDeviceBatch b) {
     const uint32_t first = b.seq_sub[im.seq_off + seq];
     const Geo g = interval_geo(b.ivl_start + im.ivl_off, iv, S);
     const uint32_t n = min(g.nsub - first, (uint32_t) MJ_SEQ_SUBS);
-    const MjScanCtx cx = make_ctx(b, im, s_tabs);
+    const MjScanCtx cx = make_ctx(b, im);
 
     const bool valid = lane < n;
     const uint32_t j = first + lane;
@@ -181,7 +195,8 @@ __global__ __launch_bounds__(TPB) void mj_k_entropy_sync(MjDeviceBatch b) {
 
     /* round 0: cold start at the subsequence boundary (exact for the interval's first) */
     LaneRec rec = {start, 0, 0, 0, 0, 0, 0};
-    if (valid) rec = decode_nowrite(cx, start, 0, end_own);
+    int32_t *acc = lds_dc(b) + wave * 64 * MJ_MAX_COMP + lane;
+    if (valid) rec = decode_nowrite(cx, start, 0, end_own, acc);
     uint32_t carry_p = rec.p, carry_kc = rec.kc;
     bool active = valid && (lane + 1 < n);
     uint32_t rounds = 0;
@@ -189,7 +204,7 @@ __global__ __launch_bounds__(TPB) void mj_k_entropy_sync(MjDeviceBatch b) {
         if (!__any(active) || (b.dbg & 2u)) break;
         rounds++;
         LaneRec out = rec;
-        if (active) out = decode_nowrite(cx, carry_p, carry_kc, sub_end(g, j + r, S));
+        if (active) out = decode_nowrite(cx, carry_p, carry_kc, sub_end(g, j + r, S), acc);
         /* lane m = l + r takes what lane l produced for subsequence m */
         const LaneRec in = shfl_up_rec(out, (int) r);
         const int in_active = __shfl_up((int) active, (int) r, 64);
@@ -229,7 +244,6 @@ __global__ __launch_bounds__(TPB) void mj_k_entropy_sync(MjDeviceBatch b) {
 constexpr int FIX_TPB = 1024;
 
 __global__ __launch_bounds__(FIX_TPB) void mj_k_entropy_fix(MjDeviceBatch b) {
-    MjHuffDev *s_tabs = reinterpret_cast<MjHuffDev *>(s_dyn);
     __shared__ int s_changed;
     __shared__ uint32_t s_part[FIX_TPB * 5];
     const uint32_t n_multi = min(*b.multi_count, b.n_multi_cap);
@@ -240,9 +254,10 @@ __global__ __launch_bounds__(FIX_TPB) void mj_k_entropy_fix(MjDeviceBatch b) {
     const uint32_t S = im.sub_bits;
     const Geo g = interval_geo(b.ivl_start + im.ivl_off, iv, S);
     const uint32_t seq_first = im.seq_off + b.ivl_seq[im.ivl_off + iv]; /* global slot of the interval's first sequence */
-    load_tables(s_tabs, b.sets[im.huff_set]);
+    load_tables(b, im);
     __syncthreads();
-    const MjScanCtx cx = make_ctx(b, im, s_tabs);
+    const MjScanCtx cx = make_ctx(b, im);
+    int32_t *fix_acc = lds_dc(b) + (threadIdx.x >> 6) * 64 * MJ_MAX_COMP + (threadIdx.x & 63);
     MjSubRec *rec = b.rec + (uint64_t) seq_first * MJ_SEQ_SUBS;
 
     /* Boundary q (1 <= q < nseq): the decoder that leaves sequence q-1 continues
@@ -272,7 +287,7 @@ __global__ __launch_bounds__(FIX_TPB) void mj_k_entropy_fix(MjDeviceBatch b) {
             const uint32_t first = q * MJ_SEQ_SUBS;
             const uint32_t n = min(g.nsub - first, (uint32_t) MJ_SEQ_SUBS);
             for (uint32_t l = 0; l < n; l++) {
-                const LaneRec o = decode_nowrite(cx, p, kc, sub_end(g, first + l, S));
+                const LaneRec o = decode_nowrite(cx, p, kc, sub_end(g, first + l, S), fix_acc);
                 MjSubRec *dst = rec + (uint64_t) first + l;
                 const MjState old = dst->exit;
                 MjSubRec w;
@@ -367,12 +382,11 @@ __global__ __launch_bounds__(FIX_TPB) void mj_k_entropy_fix(MjDeviceBatch b) {
 /* ------------------------------------------------------------------------ */
 /* kernel 3: writing pass, all sequences                                    */
 /* ------------------------------------------------------------------------ */
-constexpr int BLK_STRIDE = 144;   /* bytes per lane block buffer: 128 + 16, conflict-free 16-byte reads */
+constexpr int BLK_STRIDE = 128;   /* bytes per lane block buffer (unpadded: LDS capacity decides the occupancy here) */
 
 __global__ __launch_bounds__(TPB) void mj_k_entropy_write(MjDeviceBatch b) {
-    /* dynamic LDS: [tables][block buffers: TPB x 144 B][flush lists: TPB x (4 + 4) B] */
-    MjHuffDev *s_tabs = reinterpret_cast<MjHuffDev *>(s_dyn);
-    unsigned char *s_blk = s_dyn + b.max_ntab * sizeof(MjHuffDev);
+    /* dynamic LDS: [tables][slots][block buffers: TPB x 144 B][flush lists: TPB x (4 + 4) B] */
+    unsigned char *s_blk = lds_after_dc(b);
     uint32_t *s_list_blk = reinterpret_cast<uint32_t *>(s_blk + TPB * BLK_STRIDE);
     uint32_t *s_list_lane = s_list_blk + TPB;
 
@@ -381,7 +395,7 @@ __global__ __launch_bounds__(TPB) void mj_k_entropy_write(MjDeviceBatch b) {
     const uint32_t n_seq = b.dyn[ii].n_seq;
     const uint32_t seq0 = (blockIdx.x - im.wg_first) * WAVES;
     if (seq0 >= n_seq) return;
-    load_tables(s_tabs, b.sets[im.huff_set]);
+    load_tables(b, im);
     {   /* zero the block buffers */
         uint4 *z = reinterpret_cast<uint4 *>(s_blk);
         for (uint32_t i = threadIdx.x; i < TPB * BLK_STRIDE / 16; i += TPB) z[i] = make_uint4(0, 0, 0, 0);
@@ -397,7 +411,7 @@ __global__ __launch_bounds__(TPB) void mj_k_entropy_write(MjDeviceBatch b) {
     const uint32_t first = b.seq_sub[im.seq_off + seq];
     const Geo g = interval_geo(b.ivl_start + im.ivl_off, iv, S);
     const uint32_t n = min(g.nsub - first, (uint32_t) MJ_SEQ_SUBS);
-    const MjScanCtx cx = make_ctx(b, im, s_tabs);
+    const MjScanCtx cx = make_ctx(b, im);
     const bool valid = lane < n;
     const MjSubRec r = b.rec[(uint64_t) (im.seq_off + seq) * MJ_SEQ_SUBS + lane];
 
@@ -428,10 +442,11 @@ __global__ __launch_bounds__(TPB) void mj_k_entropy_write(MjDeviceBatch b) {
 
     uint32_t k = kc & 0xFFu, c = kc >> 8;
     uint32_t blk = se.blk + nb;
-    d0 += se.pred[0];
-    d1 += se.pred[1];
-    d2 += se.pred[2];
-    d3 += se.pred[3];
+    int32_t *acc = lds_dc(b) + wave * 64 * MJ_MAX_COMP + lane;
+    acc[0] = d0 + se.pred[0];
+    acc[64] = d1 + se.pred[1];
+    acc[128] = d2 + se.pred[2];
+    acc[192] = d3 + se.pred[3];
     bool skip = (k != 0);
     const uint32_t end = sub_end(g, first + lane, S);
     int16_t *blkbuf = reinterpret_cast<int16_t *>(s_blk + (wave * 64 + lane) * BLK_STRIDE);
@@ -440,15 +455,15 @@ __global__ __launch_bounds__(TPB) void mj_k_entropy_write(MjDeviceBatch b) {
     unsigned char *coef_bytes = reinterpret_cast<unsigned char *>(cx.coefs);
     const uint32_t store_end = (b.dbg & 4u) ? 0u : blk_end;
 
-    MjBits bw;
+    MjLane L;
     bool live = valid && mj_write_live(p, k, skip, end, g.b1);
-    if (live) mj_bits_init(bw, cx.stream, p);
+    if (live) mj_lane_init(cx, L, p, k, c);
     while (__any(live)) {
         bool fin = false;
         uint32_t fin_blk = 0;
         if (live) {
-            mj_write_step(cx, bw, p, k, c, skip, blk, blk_end, d0, d1, d2, d3, blkbuf, fin, fin_blk);
-            live = mj_write_live(p, k, skip, end, g.b1);
+            mj_write_step(cx, L, skip, blk, blk_end, acc, 64, blkbuf, fin, fin_blk);
+            live = mj_write_live(L.p, L.k, skip, end, g.b1);
         }
         const unsigned long long mask = __ballot(fin);
         if (mask) {
@@ -479,48 +494,60 @@ __global__ __launch_bounds__(TPB) void mj_k_entropy_write(MjDeviceBatch b) {
 /* diagnostic: one lane per restart interval, no subsequence machinery      */
 /* ------------------------------------------------------------------------ */
 __global__ __launch_bounds__(TPB) void mj_k_entropy_serial(MjDeviceBatch b) {
-    MjHuffDev *s_tabs = reinterpret_cast<MjHuffDev *>(s_dyn);
     const uint32_t ii = blockIdx.x;
     const MjImageDev &im = b.img[ii];
-    load_tables(s_tabs, b.sets[im.huff_set]);
+    load_tables(b, im);
     __syncthreads();
-    const MjScanCtx cx = make_ctx(b, im, s_tabs);
+    const MjScanCtx cx = make_ctx(b, im);
     const uint32_t *ivl = b.ivl_start + im.ivl_off;
     const uint32_t n_blocks = im.n_mcu * im.bpm;
     for (uint32_t iv = threadIdx.x; iv < im.n_ivl; iv += TPB) {
-        const uint32_t blk_base = iv * im.ri * im.bpm;
-        const uint32_t blk_end = min(blk_base + im.ri * im.bpm, n_blocks);
-        write_pass(cx, ivl[iv] * 8u, 0, ivl[iv + 1] * 8u, blk_base, blk_end, 0, 0, 0, 0);
+        uint32_t blk = iv * im.ri * im.bpm;
+        const uint32_t blk_end = min(blk + im.ri * im.bpm, n_blocks);
+        const uint32_t p0 = ivl[iv] * 8u, end = ivl[iv + 1] * 8u;
+        if (p0 >= end) continue;
+        MjLane L;
+        mj_lane_init(cx, L, p0, 0, 0);
+        int32_t *acc = lds_dc(b) + (threadIdx.x >> 6) * 64 * MJ_MAX_COMP + (threadIdx.x & 63);
+        acc[0] = acc[64] = acc[128] = acc[192] = 0;
+        while (L.p < end && blk < blk_end) {
+            mj_refill(cx, L);
+            const MjSym s = mj_step<true>(cx, L);
+            int32_t v = s.val;
+            if (s.dc) v = mj_dc_add(acc, 64, s.comp, s.val);
+            if (s.store) cx.coefs[(uint64_t) blk * 64 + s.kpos] = (int16_t) v;
+            blk += s.done ? 1u : 0u;
+        }
     }
 }
 
 }  // namespace
 
-static size_t table_lds(const MjDeviceBatch &b) {
-    return (size_t) b.max_ntab * sizeof(MjHuffDev);
+static size_t table_lds(const MjDeviceBatch &b, uint32_t waves) {
+    return (size_t) b.max_ntab * sizeof(MjHuffDev) + 16 * sizeof(uint32_t) + (size_t) waves * 64 * MJ_MAX_COMP * sizeof(int32_t);
 }
 
 hipError_t mj_launch_entropy(const MjDeviceBatch &b, hipStream_t s) {
     if (b.n_entropy_wg == 0) return hipSuccess;
-    hipLaunchKernelGGL(mj_k_entropy_sync, dim3(b.n_entropy_wg), dim3(TPB), table_lds(b), s, b);
+    hipLaunchKernelGGL(mj_k_entropy_sync, dim3(b.n_entropy_wg), dim3(TPB), table_lds(b, WAVES), s, b);
     return hipGetLastError();
 }
 
 hipError_t mj_launch_entropy_fix(const MjDeviceBatch &b, hipStream_t s) {
     if (b.n_multi_cap == 0 || b.n_entropy_wg == 0) return hipSuccess;
-    hipLaunchKernelGGL(mj_k_entropy_fix, dim3(b.n_multi_cap), dim3(FIX_TPB), table_lds(b), s, b);
+    hipLaunchKernelGGL(mj_k_entropy_fix, dim3(b.n_multi_cap), dim3(FIX_TPB), table_lds(b, FIX_TPB / 64), s, b);
     return hipGetLastError();
 }
 
 hipError_t mj_launch_entropy_write(const MjDeviceBatch &b, hipStream_t s) {
     if (b.n_entropy_wg == 0) return hipSuccess;
-    const size_t lds = table_lds(b) + (size_t) TPB * BLK_STRIDE + (size_t) TPB * 8;
+    const size_t lds = table_lds(b, WAVES) + (size_t) TPB * BLK_STRIDE + (size_t) TPB * 8;
     hipLaunchKernelGGL(mj_k_entropy_write, dim3(b.n_entropy_wg), dim3(TPB), lds, s, b);
     return hipGetLastError();
 }
 
 hipError_t mj_launch_entropy_serial(const MjDeviceBatch &b, hipStream_t s) {
     if (b.n_img == 0) return hipSuccess;
-    hipLaunchKernelGGL(mj_k_entropy_serial, dim3(b.n_img), dim3(TPB), table_lds(b), s, b);
+    hipLaunchKernelGGL(mj_k_entropy_serial, dim3(b.n_img), dim3(TPB), table_lds(b, WAVES), s, b);
     return hipGetLastError();
 }

@@ -121,29 +121,53 @@ void mj_parsed_free(MjParsed *p) {
     memset(p, 0, sizeof *p);
 }
 
-void mj_flatten_huff(const HuffTable *ht, MjHuffDev *out) {
+void mj_flatten_huff(const HuffTable *ht, MjHuffDev *out, MjHuffWalk *walk) {
     memset(out, 0, sizeof *out);
-    out->maxcode[0] = -1;
+    memset(walk, 0, sizeof *walk);
+    walk->maxcode[0] = -1;
     int nvals = 0;
+    uint32_t nsub = 0;
     for (int l = 1; l <= 16; l++) {
         int n = ht->len[l - 1];
         if (n == 0 || ht->symbols[l - 1] == NULL) {
-            out->maxcode[l] = -1;
-            out->valoff[l] = 0;
+            walk->maxcode[l] = -1;
+            walk->valoff[l] = 0;
             continue;
         }
         int mincode = (uint16_t) ht->min_codes[l - 1];
-        out->maxcode[l] = mincode + n - 1;
-        out->valoff[l] = nvals - mincode;
+        walk->maxcode[l] = mincode + n - 1;
+        walk->valoff[l] = nvals - mincode;
         for (int i = 0; i < n && nvals < 256; i++, nvals++) {
             uint8_t sym = ht->symbols[l - 1][i];
-            out->vals[nvals] = sym;
+            uint32_t code = (uint32_t) (mincode + i);
+            walk->vals[nvals] = sym;
             if (l <= MJ_LUT_BITS) {
-                /* every LUT index whose leading l bits are this code */
-                uint32_t first = (uint32_t) (mincode + i) << (MJ_LUT_BITS - l);
+                /* every first-level index whose leading l bits are this code */
+                uint32_t first = code << (MJ_LUT_BITS - l);
                 uint32_t count = 1u << (MJ_LUT_BITS - l);
                 for (uint32_t j = 0; j < count && first + j < MJ_LUT_SIZE; j++) {
                     out->lut[first + j] = (uint16_t) ((l << 8) | sym);
+                }
+            } else {
+                /* long code: its first MJ_LUT_BITS bits pick a second-level table */
+                uint32_t prefix = (code >> (l - MJ_LUT_BITS)) & (MJ_LUT_SIZE - 1);
+                uint16_t e = out->lut[prefix];
+                uint32_t si;
+                if ((e & 0xFF00u) == MJ_LUT_LONG) {
+                    si = e & 0xFFu;
+                } else if (e == 0 && nsub < MJ_SUB_MAX) {
+                    si = nsub++;
+                    out->lut[prefix] = (uint16_t) (MJ_LUT_LONG | si);
+                } else {
+                    /* no room (or a malformed table): the whole prefix goes to the canonical walk */
+                    if (e == 0) out->lut[prefix] = (uint16_t) MJ_LUT_WALK;
+                    continue;
+                }
+                uint32_t rem = (uint32_t) l - MJ_LUT_BITS;   /* 1..MJ_SUB_BITS bits of the code index the table */
+                uint32_t first = (code & ((1u << rem) - 1u)) << (MJ_SUB_BITS - rem);
+                uint32_t count = 1u << (MJ_SUB_BITS - rem);
+                for (uint32_t j = 0; j < count && first + j < MJ_SUB_SIZE; j++) {
+                    out->sub[si][first + j] = (uint16_t) ((l << 8) | sym);
                 }
             }
         }
@@ -241,11 +265,13 @@ int mj_flatten_image(const MjParsed *p, size_t file_len, MjImageDev *img, MjHuff
         }
         if (dc_slot[td] < 0) {
             dc_slot[td] = (int) set->ntab;
-            mj_flatten_huff(&p->hts.DCAC[TC_DC][td], &set->tab[set->ntab++]);
+            mj_flatten_huff(&p->hts.DCAC[TC_DC][td], &set->tab[set->ntab], &set->walk[set->ntab]);
+            set->ntab++;
         }
         if (ac_slot[ta] < 0) {
             ac_slot[ta] = (int) set->ntab;
-            mj_flatten_huff(&p->hts.DCAC[TC_AC][ta], &set->tab[set->ntab++]);
+            mj_flatten_huff(&p->hts.DCAC[TC_AC][ta], &set->tab[set->ntab], &set->walk[set->ntab]);
+            set->ntab++;
         }
         const Component *c = &fh->cs[ci];
         for (int v = 0; v < c->vsf; v++) {
