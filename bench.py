@@ -144,7 +144,8 @@ def main():
     except AttributeError:
         host_cores = os.cpu_count() or 1
     workers = args.gen_workers if args.gen_workers > 0 else max(1, min(16, host_cores // max(1, world)))
-    seeds = [rank * args.batch + i for i in range(args.batch)]
+    from jpeg_decoder_amd.shard import reduce_run, shard_seeds
+    seeds = shard_seeds(args.batch, rank, world)
     t0 = time.perf_counter()
     files = generate(config, seeds, workers)
     t_gen = time.perf_counter() - t0
@@ -191,14 +192,12 @@ def main():
     stats = batch.entropy_stats()
     pixels_rank = args.batch * width * height
     comp_bytes_rank = sum(len(f) for f in files)
-    red = torch.tensor([float(pixels_rank), float(args.batch), float(comp_bytes_rank)], device="cuda",
-                       dtype=torch.float64)
-    tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(red, op=dist.ReduceOp.SUM)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    total_pixels, total_images, total_bytes = [float(v) for v in red.tolist()]
-    elapsed_max = float(tmax.item())
+    knames = sorted(kms)
+    tot = reduce_run(pixels_rank, args.batch, comp_bytes_rank, 0.0, elapsed,
+                     [kms[k][0] / max(kms[k][1], 1) for k in knames], device="cuda")
+    total_pixels, total_images, total_bytes = tot.pixels, tot.images, tot.comp_bytes
+    elapsed_max = tot.elapsed_max
+    kernel_ms_max = dict(zip(knames, tot.kernel_ms_max))
 
     if rank == 0:
         value = total_pixels * args.steps / elapsed_max / 1e6
@@ -249,6 +248,7 @@ def main():
                                "frac_of_peak": round((comp_bytes_rank / pixels_rank + 4 * spp + 3) * value * 1e6 / world
                                                      / (HBM_PEAK_GBS * 1e9), 4)},
             "kernels": kernels,
+            "kernels_max_over_ranks_ms": {k: round(v, 4) for k, v in kernel_ms_max.items()},
             "host": {"generate_s": round(t_gen, 2), "prepare_h2d_s": round(t_prepare, 3),
                      "MPps_incl_prepare": round(pixels_rank / 1e6 / (t_prepare + ms_step * 1e-3), 1)},
         }

@@ -1,0 +1,21 @@
+#!/bin/bash
+# Collect the per-kernel evidence for one round on the GPU box:
+#   profiles/collect.sh <tag>      (run from the repository root, through gpurun)
+# writes gpurun_out/<tag>/{bench.json, stats/, pmc_fetch/, pmc_write/, pmc_sq/}.
+# Each GPU step runs under its own time limit and the chain stops at the first failure.
+# Counter passes run alone (kernel trace + stats only in the timing pass).
+set -o pipefail
+tag=${1:-prof}
+out=gpurun_out/$tag
+mkdir -p "$out"
+export TMPDIR=/tmp
+B="bench.py --steps 10 --warmup 2 --no-cpu-baseline --gen-workers 1"
+timeout -k 10 300 python3 -u bench.py --steps 20 --warmup 3 > "$out/bench.json" 2> "$out/bench.err" &&
+timeout -k 10 200 rocprofv3 --kernel-trace --stats -d "$out/stats" -o run -- python3 $B > "$out/stats.log" 2>&1 &&
+timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d "$out/pmc_fetch" -o run -- python3 $B > "$out/pmc_fetch.log" 2>&1 &&
+timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d "$out/pmc_write" -o run -- python3 $B > "$out/pmc_write.log" 2>&1 &&
+timeout -s KILL 200 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY -d "$out/pmc_sq" -o run -- python3 $B > "$out/pmc_sq.log" 2>&1
+rc=$?
+echo "collect rc=$rc"
+ls -R "$out" | head -40
+exit $rc
