@@ -122,8 +122,9 @@ int mj_batch_kernel_ms(mj_batch *b, float ms[MJ_T_COUNT], int launches[MJ_T_COUN
 int mj_batch_reset_timing(mj_batch *b);
 
 /* Entropy-stage statistics of the last decode (device counters, read back):
- * [0] subsequences, [1] sync rounds summed over sequences, [2] max rounds in a
- * sequence, [3] sequences, [4] multi-sequence intervals, [5] fix-up iterations. */
+ * [0] subsequences, [1] synchronisation rounds summed over workgroups, [2] max rounds
+ * in a workgroup, [3] sequences, [4] multi-sequence intervals, [5] fix-up iterations,
+ * [6] subsequence decodes spent in the rounds, [7] workgroups that ran. */
 int mj_batch_entropy_stats(mj_batch *b, int64_t stats[8]);
 
 #ifdef __cplusplus

@@ -186,7 +186,7 @@ class Batch:
         st = (C.c_int64 * 8)()
         _check(self.lib, self.lib.mj_batch_entropy_stats(self.h, st), "mj_batch_entropy_stats")
         keys = ["subsequences", "rounds_sum", "rounds_max", "sequences", "multi_seq_intervals", "fix_iterations",
-                "r6", "r7"]
+                "round_tasks", "workgroups"]
         return dict(zip(keys, [int(v) for v in st]))
 
     def close(self):
@@ -212,12 +212,12 @@ class Emu:
         self.lib.mj_emu_decode_coefs.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_int64, C.c_uint32,
                                                  C.POINTER(C.c_int64)]
 
-    def decode_coefs(self, data, n_blocks_cap, sub_bits=0):
+    def decode_coefs(self, data, n_blocks_cap, sub_bits=0, lane_subs=0):
         out = np.zeros((n_blocks_cap, 64), np.int16)
-        st = (C.c_int64 * 8)()
-        n = self.lib.mj_emu_decode_coefs(data, len(data), out.ctypes.data, n_blocks_cap, sub_bits, st)
+        st = (C.c_int64 * 16)()
+        n = self.lib.mj_emu_decode_coefs(data, len(data), out.ctypes.data, n_blocks_cap, sub_bits | (lane_subs << 16), st)
         if n < 0:
             raise RuntimeError("mj_emu_decode_coefs failed")
         keys = ["subsequences", "rounds_sum", "rounds_max", "sequences", "multi_seq_intervals", "fix_iterations",
-                "sub_bits", "n_rst"]
+                "sub_bits", "n_rst", "lane_subs", "round_tasks"]
         return out[:n], dict(zip(keys, [int(v) for v in st]))

@@ -225,7 +225,7 @@ static int batch_build(mj_ctx *ctx, std::vector<MjPrepared> &prep, uint32_t flag
     b->info.resize(n);
 
     uint64_t raw_total = 0, cmp_total = 0, coef_blocks = 0, rgb_total = 0, plane_total = 0;
-    uint64_t n_tiles = 0, n_ivl = 0, n_seq = 0, n_wg = 0, n_multi = 0, n_idct = 0;
+    uint64_t n_tiles = 0, n_ivl = 0, n_seq = 0, n_rec = 0, n_wg = 0, n_multi = 0, n_idct = 0;
     std::vector<uint32_t> tile_img, wg_img, idct_img, idct_first(n);
 
     for (int i = 0; i < n; i++) {
@@ -262,12 +262,15 @@ static int batch_build(mj_ctx *ctx, std::vector<MjPrepared> &prep, uint32_t flag
         n_tiles += im.n_tiles;
         im.ivl_off = (uint32_t) n_ivl;
         n_ivl += im.n_ivl + 1;
-        const uint64_t seq_bits = (uint64_t) MJ_SEQ_SUBS * im.sub_bits;
+        const uint64_t seq_subs = (uint64_t) MJ_SEQ_LANES * im.lane_subs;
+        const uint64_t seq_bits = seq_subs * im.sub_bits;
         im.seq_cap = (uint32_t) ((im.raw_len * 8 + seq_bits - 1) / seq_bits + im.n_ivl);
         im.seq_off = (uint32_t) n_seq;
         n_seq += im.seq_cap;
+        im.rec_off = (uint32_t) n_rec;
+        n_rec += im.seq_cap * seq_subs;
         im.wg_first = (uint32_t) n_wg;
-        const uint32_t wgs = (im.seq_cap + 3) / 4;
+        const uint32_t wgs = (im.seq_cap + MJ_WG_SEQS - 1) / MJ_WG_SEQS;
         n_wg += wgs;
         uint64_t mc = im.raw_len * 8 / seq_bits;
         im.multi_cap = (uint32_t) (mc < im.n_ivl ? mc : im.n_ivl);
@@ -278,7 +281,7 @@ static int batch_build(mj_ctx *ctx, std::vector<MjPrepared> &prep, uint32_t flag
         tile_img.insert(tile_img.end(), im.n_tiles, (uint32_t) i);
         wg_img.insert(wg_img.end(), wgs, (uint32_t) i);
         idct_img.insert(idct_img.end(), iw, (uint32_t) i);
-        if (n_tiles >= (1ull << 31) || n_seq >= (1ull << 31) || n_idct >= (1ull << 31) || n_ivl >= (1ull << 31)) {
+        if (n_tiles >= (1ull << 31) || n_seq >= (1ull << 31) || n_rec >= (1ull << 31) || n_idct >= (1ull << 31) || n_ivl >= (1ull << 31)) {
             mj_batch_destroy(b);
             return set_err("mj_batch_create: batch too large");
         }
@@ -313,7 +316,7 @@ static int batch_build(mj_ctx *ctx, std::vector<MjPrepared> &prep, uint32_t flag
     d.n_multi_cap = (uint32_t) n_multi;
     d.n_idct_wg = (uint32_t) n_idct;
     d.want_planes = (flags & MJ_WANT_PLANES) ? 1u : 0u;
-    d.dbg = (flags >> 16) & 0xFFu;
+    d.dbg = (flags >> 16) & 0xFFFFu;
     d.max_ntab = 1;
     for (const MjHuffSet &hs : b->sets) d.max_ntab = hs.ntab > d.max_ntab ? hs.ntab : d.max_ntab;
     b->coef_bytes = coef_blocks * 128;
@@ -340,7 +343,7 @@ static int batch_build(mj_ctx *ctx, std::vector<MjPrepared> &prep, uint32_t flag
     rc |= dev_alloc(b, &d.ivl_seq, n_ivl, true);
     rc |= dev_alloc(b, &d.seq_ivl, n_seq, true);
     rc |= dev_alloc(b, &d.seq_sub, n_seq, true);
-    rc |= dev_alloc(b, &d.rec, n_seq * MJ_SEQ_SUBS, true);
+    rc |= dev_alloc(b, &d.rec, n_rec, true);
     rc |= dev_alloc(b, &d.seq_entry, n_seq, true);
     rc |= dev_alloc(b, &d.seq_seen, n_seq, true);
     rc |= dev_alloc(b, &d.seq_flag, n_seq, true);

@@ -13,7 +13,8 @@
 #define MJ_MAX_TABS 8          /* Huffman tables one scan can reference */
 #define MJ_LUT_BITS 10
 #define MJ_LUT_SIZE (1 << MJ_LUT_BITS)
-#define MJ_SEQ_SUBS 64         /* subsequences per sequence = lanes per wavefront */
+#define MJ_SEQ_LANES 64        /* lanes per wavefront; a sequence is MJ_SEQ_LANES * lane_subs subsequences */
+#define MJ_MAX_LANE_SUBS 8
 #define MJ_SCAN_TILE 4096      /* raw bytes per scan-kernel workgroup */
 #define MJ_STREAM_PAD 64       /* readable zero bytes after every compacted stream */
 #define MJ_NO_TERMINATOR 0xFFFFFFFFu
@@ -60,7 +61,7 @@ typedef struct {
     uint32_t mcus_x, mcus_y, n_mcu, bpm;
     uint32_t ri;         /* MCUs per restart interval; n_mcu when the file has no DRI */
     uint32_t n_ivl;      /* ceil(n_mcu / ri) */
-    uint32_t sub_bits;   /* subsequence length in bits, multiple of 32 */
+    uint32_t sub_bits;   /* subsequence length in bits, multiple of 32: one record per subsequence */
     uint32_t huff_set;   /* index into the batch's MjHuffSet array */
     uint32_t pitch;      /* RGB row pitch in bytes */
     /* per block slot of one MCU, in scan order (decode.c:591-611) */
@@ -84,6 +85,8 @@ typedef struct {
     uint32_t seq_cap;    /* sequence slots reserved (upper bound) */
     uint32_t wg_first;   /* first entropy workgroup of this image */
     uint32_t multi_cap;  /* upper bound on intervals longer than one sequence */
+    uint32_t lane_subs;  /* consecutive subsequences one lane decodes (1..MJ_MAX_LANE_SUBS) */
+    uint32_t rec_off;    /* first subsequence record of the image; sequence q starts at rec_off + q * 64 * lane_subs */
     uint32_t pad_;
 } MjImageDev;
 

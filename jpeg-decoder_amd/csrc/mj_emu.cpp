@@ -5,6 +5,7 @@
  * in production) has CPU test coverage, and to measure how many synchronisation
  * rounds real streams need.  It is not reachable from the decode entry points.
  */
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -76,7 +77,9 @@ extern "C" {
  * coefs: n_blocks*64 int16 (caller-allocated, zeroed here).  force_sub_bits: 0 =
  * the library's own choice.  stats[0] subsequences, [1] rounds summed over
  * sequences, [2] max rounds, [3] sequences, [4] multi-sequence intervals,
- * [5] fix-up iterations (max over intervals), [6] sub_bits used.
+ * [5] fix-up iterations (max over intervals), [6] sub_bits used, [7] restart markers
+ * found, [8] subsequences per lane, [9] subsequence decodes spent in the rounds.
+ * force_sub_bits: low 16 bits = subsequence length, high 16 bits = subsequences per lane.
  * Returns the number of blocks, or -1.
  */
 int64_t mj_emu_decode_coefs(const uint8_t *file, size_t len, int16_t *coefs, int64_t cap_blocks, uint32_t force_sub_bits,
@@ -100,10 +103,13 @@ int64_t mj_emu_decode_coefs(const uint8_t *file, size_t len, int16_t *coefs, int
         return -1;
     }
     memset(coefs, 0, (size_t) n_blocks * 64 * sizeof(int16_t));
-    if (force_sub_bits) {
-        img.sub_bits = (force_sub_bits + 31) / 32 * 32;
+    if (force_sub_bits & 0xFFFFu) {
+        img.sub_bits = ((force_sub_bits & 0xFFFFu) + 31) / 32 * 32;
     }
-    const uint32_t S = img.sub_bits;
+    if (force_sub_bits >> 16) {
+        img.lane_subs = force_sub_bits >> 16;
+    }
+    const uint32_t S = img.sub_bits, G = img.lane_subs, SQ = MJ_SEQ_LANES * G;
 
     Layout L;
     emu_scan(file + P.ent_pos, img.raw_len, img.n_ivl, L);
@@ -119,52 +125,61 @@ int64_t mj_emu_decode_coefs(const uint8_t *file, size_t len, int16_t *coefs, int
     cx.bpm = img.bpm;
     cx.wi_mask = 0xFFFFFFFFu;
 
-    int64_t st_subs = 0, st_rounds = 0, st_maxr = 0, st_seqs = 0, st_multi = 0, st_fix = 0;
+    int64_t st_subs = 0, st_rounds = 0, st_maxr = 0, st_seqs = 0, st_multi = 0, st_fix = 0, st_tasks = 0;
+    // MJ_EMU_HIST=1: print, per round, how many decoders are still out of step
+    int64_t hist_store[64] = {0};
+    int64_t *hist = getenv("MJ_EMU_HIST") ? hist_store : nullptr;
+
+    struct Task {
+        uint32_t m;   // subsequence to decode next (index within the interval)
+        Rec from;     // state to decode it from
+    };
 
     for (uint32_t iv = 0; iv < img.n_ivl; iv++) {
         const uint32_t b0 = L.ivl_start[iv] * 8, b1 = L.ivl_start[iv + 1] * 8;
         const uint32_t bits = b1 - b0;
         uint32_t nsub = (bits + S - 1) / S;
         if (nsub == 0) nsub = 1;
-        const uint32_t nseq = (nsub + MJ_SEQ_SUBS - 1) / MJ_SEQ_SUBS;
+        const uint32_t nseq = (nsub + SQ - 1) / SQ;
         st_subs += nsub;
         st_seqs += nseq;
         auto sub_end = [&](uint32_t j) { return (j + 1 == nsub) ? b1 : b0 + (j + 1) * S; };
         std::vector<Rec> rec(nsub);
 
-        // ---- kernel A: one wave per sequence, lock-step rounds -------------------
+        // ---- kernel A: per sequence, one lane per G consecutive subsequences ------
         for (uint32_t q = 0; q < nseq; q++) {
-            const uint32_t first = q * MJ_SEQ_SUBS;
-            const uint32_t n = (nsub - first < MJ_SEQ_SUBS) ? nsub - first : MJ_SEQ_SUBS;
-            std::vector<Rec> carry(n);
-            std::vector<char> active(n);
-            for (uint32_t l = 0; l < n; l++) {   // round 0: cold start
-                rec[first + l] = span(cx, b0 + (first + l) * S, 0, 0, sub_end(first + l));
-                carry[l] = rec[first + l];
-                active[l] = (l + 1 < n);
+            const uint32_t first = q * SQ;
+            const uint32_t n = (nsub - first < SQ) ? nsub - first : SQ;
+            std::vector<Task> tasks;
+            // cold pass: lane l decodes its G subsequences back to back from a cold state
+            // (exact for the interval's first lane), leaving one record per subsequence
+            for (uint32_t l = 0; l * G < n; l++) {
+                Rec cur{b0 + (first + l * G) * S, 0, 0, 0, {0, 0, 0, 0}};
+                for (uint32_t g = 0; g < G && l * G + g < n; g++) {
+                    const uint32_t j = first + l * G + g;
+                    rec[j] = span(cx, cur.p, cur.k, cur.c, sub_end(j));
+                    cur = rec[j];
+                }
+                if ((l + 1) * G < n) tasks.push_back(Task{first + (l + 1) * G, cur});
             }
+            // rounds: every decoder still out of step decodes one more subsequence, replaces
+            // its record and stops when the state it reaches equals the one recorded there before
             int64_t rounds = 0;
-            for (uint32_t r = 1; r < n; r++) {
-                bool any = false;
-                for (uint32_t l = 0; l < n; l++) any = any || active[l];
-                if (!any) break;
+            while (!tasks.empty()) {
                 rounds++;
-                // all lanes decode "simultaneously" from their carried state ...
-                std::vector<Rec> out(n);
-                for (uint32_t l = 0; l < n; l++) {
-                    if (active[l]) {
-                        out[l] = span(cx, carry[l].p, carry[l].k, carry[l].c, sub_end(first + l + r));
-                    }
+                st_tasks += (int64_t) tasks.size();
+                if (hist && rounds < 32) {
+                    hist[rounds] += (int64_t) tasks.size();
+                    hist[32 + rounds]++;
                 }
-                // ... then lane m takes what lane m-r produced for subsequence m
-                for (uint32_t l = 0; l < n; l++) {
-                    if (!active[l]) continue;
-                    const uint32_t m = l + r;
-                    const bool synced = same_state(out[l], rec[first + m]);
-                    rec[first + m] = out[l];
-                    carry[l] = out[l];
-                    if (synced || m + 1 >= n) active[l] = 0;
+                std::vector<Task> next;
+                for (const Task &t : tasks) {
+                    const Rec out = span(cx, t.from.p, t.from.k, t.from.c, sub_end(t.m));
+                    const bool synced = same_state(out, rec[t.m]);
+                    rec[t.m] = out;
+                    if (!synced && t.m + 1 < first + n) next.push_back(Task{t.m + 1, out});
                 }
+                tasks.swap(next);
             }
             st_rounds += rounds;
             if (rounds > st_maxr) st_maxr = rounds;
@@ -181,7 +196,7 @@ int64_t mj_emu_decode_coefs(const uint8_t *file, size_t len, int16_t *coefs, int
                 iters++;
                 // phase 1: every boundary reads its entry state
                 std::vector<Rec> entry(nseq);
-                for (uint32_t q = 1; q < nseq; q++) entry[q] = rec[q * MJ_SEQ_SUBS - 1];
+                for (uint32_t q = 1; q < nseq; q++) entry[q] = rec[q * SQ - 1];
                 // phase 2: boundaries whose entry changed re-decode into their sequence
                 for (uint32_t q = 1; q < nseq; q++) {
                     if (have[q] && same_state(seen[q], entry[q])) continue;
@@ -189,8 +204,8 @@ int64_t mj_emu_decode_coefs(const uint8_t *file, size_t len, int16_t *coefs, int
                     have[q] = 1;
                     changed = true;
                     Rec cur = entry[q];
-                    const uint32_t first = q * MJ_SEQ_SUBS;
-                    const uint32_t n = (nsub - first < MJ_SEQ_SUBS) ? nsub - first : MJ_SEQ_SUBS;
+                    const uint32_t first = q * SQ;
+                    const uint32_t n = (nsub - first < SQ) ? nsub - first : SQ;
                     for (uint32_t l = 0; l < n; l++) {
                         Rec o = span(cx, cur.p, cur.k, cur.c, sub_end(first + l));
                         const bool synced = same_state(o, rec[first + l]);
@@ -205,19 +220,22 @@ int64_t mj_emu_decode_coefs(const uint8_t *file, size_t len, int16_t *coefs, int
         }
 
         // ---- prefix sums + write pass (mj_k_entropy_write) --------------------------
+        // lane = G consecutive subsequences: entry state = exit of the record before its
+        // first one, counts = sums over its own records
         const uint32_t blk_base = iv * img.ri * img.bpm;
         uint32_t blk_end = blk_base + img.ri * img.bpm;
         if (blk_end > (uint32_t) n_blocks) blk_end = (uint32_t) n_blocks;
         uint32_t blk0 = blk_base;
         int32_t pred[4] = {0, 0, 0, 0};
-        for (uint32_t j = 0; j < nsub; j++) {
+        for (uint32_t j = 0; j < nsub; j += G) {
+            const uint32_t jl = (j + G < nsub) ? j + G - 1 : nsub - 1;   // the lane's last subsequence
             uint32_t p = j ? rec[j - 1].p : b0, k = j ? rec[j - 1].k : 0, c = j ? rec[j - 1].c : 0;
             uint32_t blk = blk0;
             int32_t d[4] = {pred[0], pred[1], pred[2], pred[3]};
             bool skip = (k != 0);
             int16_t buf[64];
             memset(buf, 0, sizeof buf);
-            const uint32_t end = sub_end(j);
+            const uint32_t end = sub_end(jl);
             if (mj_write_live(p, k, skip, end, b1)) {
                 MjLane L;
                 mj_lane_init(cx, L, p, k, c);
@@ -232,8 +250,15 @@ int64_t mj_emu_decode_coefs(const uint8_t *file, size_t len, int16_t *coefs, int
                 }
             }
             // what the kernel uses: the recorded counts, not the write pass's own
-            blk0 += rec[j].nb;
-            for (int i = 0; i < 4; i++) pred[i] += rec[j].d[i];
+            for (uint32_t u = j; u <= jl; u++) {
+                blk0 += rec[u].nb;
+                for (int i = 0; i < 4; i++) pred[i] += rec[u].d[i];
+            }
+        }
+    }
+    if (hist) {
+        for (int r = 1; r < 32 && hist[32 + r]; r++) {
+            fprintf(stderr, "round %d: %lld decoders in %lld sequences\n", r, (long long) hist[r], (long long) hist[32 + r]);
         }
     }
     if (stats) {
@@ -245,6 +270,8 @@ int64_t mj_emu_decode_coefs(const uint8_t *file, size_t len, int16_t *coefs, int
         stats[5] = st_fix;
         stats[6] = S;
         stats[7] = L.n_rst;
+        stats[8] = G;
+        stats[9] = st_tasks;
     }
     mj_parsed_free(&P);
     free(set);

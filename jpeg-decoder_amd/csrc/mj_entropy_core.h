@@ -243,17 +243,11 @@ MJ_HD int32_t mj_dc_add(int32_t *acc, uint32_t stride, uint32_t comp, int32_t v)
 }
 
 /*
- * Decode symbols from state (p, k, c) until p >= end, counting only: nb is advanced
- * by the number of blocks completed and every DC difference is added to its
- * component's accumulator.
+ * Decode symbols with an initialised lane until its position reaches `end`, counting
+ * only: nb is advanced by the number of blocks completed and every DC difference is
+ * added to its component's accumulator.  The lane can go on to the next span as it is.
  */
-MJ_HD void mj_decode_span(const MjScanCtx &cx, uint32_t &p, uint32_t &k, uint32_t &c, uint32_t end, uint32_t &nb,
-                          int32_t *acc, uint32_t stride) {
-    if (p >= end) {
-        return;
-    }
-    MjLane L;
-    mj_lane_init(cx, L, p, k, c);
+MJ_HD void mj_run_span(const MjScanCtx &cx, MjLane &L, uint32_t end, uint32_t &nb, int32_t *acc, uint32_t stride) {
     while (L.p < end) {
         mj_refill(cx, L);
         const MjSym s = mj_step<false>(cx, L);
@@ -262,6 +256,17 @@ MJ_HD void mj_decode_span(const MjScanCtx &cx, uint32_t &p, uint32_t &k, uint32_
         }
         nb += s.done ? 1u : 0u;
     }
+}
+
+/* The same from a bare state (p, k, c), which is updated. */
+MJ_HD void mj_decode_span(const MjScanCtx &cx, uint32_t &p, uint32_t &k, uint32_t &c, uint32_t end, uint32_t &nb,
+                          int32_t *acc, uint32_t stride) {
+    if (p >= end) {
+        return;
+    }
+    MjLane L;
+    mj_lane_init(cx, L, p, k, c);
+    mj_run_span(cx, L, end, nb, acc, stride);
     p = L.p;
     k = L.k;
     c = L.c;

@@ -23,12 +23,16 @@ struct MjTileBase {
 };
 
 /* entropy statistics (device counters) */
-enum { MJ_ST_SUBS = 0, MJ_ST_ROUNDS, MJ_ST_MAXROUNDS, MJ_ST_SEQS, MJ_ST_MULTI, MJ_ST_FIXITERS, MJ_ST_COUNT = 8 };
+enum { MJ_ST_SUBS = 0, MJ_ST_ROUNDS, MJ_ST_MAXROUNDS, MJ_ST_SEQS, MJ_ST_MULTI, MJ_ST_FIXITERS, MJ_ST_TASKS, MJ_ST_WGS, MJ_ST_COUNT = 8 };
+
+/* sequences (wavefronts) per workgroup of the synchronisation kernel; the writing
+ * kernel runs two workgroups of half that per group */
+#define MJ_WG_SEQS 8
 
 struct MjDeviceBatch {
     uint32_t n_img;
     uint32_t n_tiles;        /* scan tiles over the whole batch */
-    uint32_t n_entropy_wg;   /* entropy workgroups (4 sequences each) */
+    uint32_t n_entropy_wg;   /* entropy workgroups (MJ_WG_SEQS sequences each) */
     uint32_t n_multi_cap;    /* capacity of the multi-sequence interval list */
     uint32_t n_idct_wg;      /* dequant+IDCT+colour workgroups */
     uint32_t want_planes;
@@ -47,7 +51,7 @@ struct MjDeviceBatch {
     uint32_t *ivl_seq;       /* per interval: image-local index of its first sequence */
     uint32_t *seq_ivl;       /* per sequence slot: interval (image-local) */
     uint32_t *seq_sub;       /* per sequence slot: first subsequence within the interval */
-    MjSubRec *rec;           /* per sequence slot: 64 subsequence records */
+    MjSubRec *rec;           /* per image from rec_off: 64 * lane_subs subsequence records per sequence slot */
     MjSeqEntry *seq_entry;   /* per sequence slot */
     MjState *seq_seen;       /* per sequence slot: entry state the fix-up last decoded from */
     uint32_t *seq_flag;      /* per sequence slot: scratch for the fix-up */

@@ -18,11 +18,16 @@
  *     prefix sum over them gives every lane the block index and DC predictors it
  *     starts with for the final, writing pass.
  *
- * One wavefront owns one *sequence* of up to 64 consecutive subsequences of one
- * interval; the four wavefronts of a workgroup share the image's Huffman lookup
- * tables in LDS.
- *   mj_k_entropy_sync   cold decode + lock-step synchronisation rounds (cross-lane
- *                       shuffles), one 32-byte record per subsequence to HBM;
+ * A lane covers lane_subs consecutive subsequences and leaves one record at the end
+ * of each, so a decoder that continues past its own lane can stop at the first record
+ * it agrees with.  One wavefront owns one *sequence* of up to 64 lanes of one
+ * interval; the wavefronts of a workgroup share the image's Huffman lookup tables in
+ * LDS.
+ *   mj_k_entropy_sync   cold decode of every lane, then rounds: every decoder still
+ *                       out of step decodes one more subsequence.  The decoders left
+ *                       in a round are few and scattered, so they are queued in LDS
+ *                       and packed into as few wavefronts as hold them; one 32-byte
+ *                       record per subsequence in HBM;
  *   mj_k_entropy_fix    only for intervals longer than one sequence (scans without
  *                       restart markers): cross-sequence synchronisation and the
  *                       prefix over sequences;
@@ -35,13 +40,17 @@
  * The kernels are latency / issue bound (dependent LDS lookups per symbol); the
  * figure of merit is decoded bits per second, not an HBM roofline.
  */
+#include <cstdlib>
+
 #include "mj_entropy_core.h"
 #include "mj_internal.h"
 
 namespace {
 
-constexpr int WAVES = 4;
+constexpr int WAVES = 4;             /* writing, serial kernels */
 constexpr int TPB = WAVES * 64;
+constexpr int SYNC_WAVES = MJ_WG_SEQS;
+constexpr int SYNC_TPB = SYNC_WAVES * 64;
 
 struct Geo {          /* wave-uniform geometry of one interval */
     uint32_t b0, b1;  /* bit range in the compacted stream */
@@ -49,43 +58,43 @@ struct Geo {          /* wave-uniform geometry of one interval */
     uint32_t nseq;
 };
 
-__device__ __forceinline__ Geo interval_geo(const uint32_t *ivl, uint32_t iv, uint32_t S) {
+__device__ __forceinline__ Geo interval_geo(const uint32_t *ivl, uint32_t iv, uint32_t S, uint32_t SQ) {
     Geo g;
     const uint32_t a = ivl[iv], e = ivl[iv + 1];
     g.b0 = a * 8u;
     g.b1 = (e > a ? e : a) * 8u;
     g.nsub = (g.b1 - g.b0 + S - 1) / S;
     if (g.nsub == 0) g.nsub = 1;
-    g.nseq = (g.nsub + MJ_SEQ_SUBS - 1) / MJ_SEQ_SUBS;
+    g.nseq = (g.nsub + SQ - 1) / SQ;
     return g;
 }
 
-__device__ __forceinline__ uint32_t sub_end(const Geo &g, uint32_t j, uint32_t S) {
-    return (j + 1 >= g.nsub) ? g.b1 : g.b0 + (j + 1) * S;
+__device__ __forceinline__ uint32_t sub_end(uint32_t b0, uint32_t b1, uint32_t nsub, uint32_t j, uint32_t S) {
+    return (j + 1 >= nsub) ? b1 : b0 + (j + 1) * S;
 }
 
 extern __shared__ __align__(16) unsigned char s_dyn[];
 
-/* LDS carve-up shared by all entropy kernels: [Huffman tables][16 slot words]... */
+/* LDS carve-up shared by all entropy kernels:
+ * [Huffman tables][16 slot words][DC accumulators: waves x 4 components x 64 lanes]... */
 __device__ __forceinline__ uint32_t *lds_slots(const MjDeviceBatch &b) {
     return reinterpret_cast<uint32_t *>(s_dyn + b.max_ntab * sizeof(MjHuffDev));
 }
-/* per-lane DC accumulators: [wave][component][lane] */
 __device__ __forceinline__ int32_t *lds_dc(const MjDeviceBatch &b) {
     return reinterpret_cast<int32_t *>(s_dyn + b.max_ntab * sizeof(MjHuffDev) + 16 * sizeof(uint32_t));
 }
-constexpr uint32_t DC_LDS_BYTES = 4u * 64u * MJ_MAX_COMP * sizeof(int32_t);   /* up to 4 waves */
-__device__ __forceinline__ unsigned char *lds_after_dc(const MjDeviceBatch &b) {
-    return reinterpret_cast<unsigned char *>(lds_dc(b)) + DC_LDS_BYTES;
+constexpr uint32_t DC_WAVE_BYTES = 64u * MJ_MAX_COMP * sizeof(int32_t);
+__device__ __forceinline__ unsigned char *lds_after_dc(const MjDeviceBatch &b, uint32_t waves) {
+    return reinterpret_cast<unsigned char *>(lds_dc(b)) + waves * DC_WAVE_BYTES;
 }
 
 /* cooperative copy of the image's Huffman tables and per-slot table selection into
  * LDS (the caller synchronises) */
 __device__ __forceinline__ void load_tables(const MjDeviceBatch &b, const MjImageDev &im) {
     const MjHuffSet &set = b.sets[im.huff_set];
-    const uint32_t n = set.ntab * (uint32_t) (sizeof(MjHuffDev) / 4);
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(set.tab);
-    uint32_t *dst = reinterpret_cast<uint32_t *>(s_dyn);
+    const uint32_t n = set.ntab * (uint32_t) (sizeof(MjHuffDev) / 16);
+    const uint4 *src = reinterpret_cast<const uint4 *>(set.tab);
+    uint4 *dst = reinterpret_cast<uint4 *>(s_dyn);
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
     if (threadIdx.x < im.bpm) {
         lds_slots(b)[threadIdx.x] = mj_slot_pack(im.blk_comp[threadIdx.x], im.blk_dc[threadIdx.x], im.blk_ac[threadIdx.x]);
@@ -109,17 +118,17 @@ struct LaneRec {      /* what a lane knows about one subsequence */
     int32_t d0, d1, d2, d3;
 };
 
-/* acc: this lane's accumulators, acc[comp * 64] */
-__device__ __forceinline__ LaneRec decode_nowrite(const MjScanCtx &cx, uint32_t p, uint32_t kc, uint32_t end, int32_t *acc) {
-    uint32_t k = kc & 0xFFu, c = kc >> 8, nb = 0;
+/* Decode with an initialised lane up to `end`; acc: this lane's accumulators, acc[comp * 64] */
+__device__ __forceinline__ LaneRec run_nowrite(const MjScanCtx &cx, MjLane &L, uint32_t end, int32_t *acc) {
+    uint32_t nb = 0;
     acc[0] = 0;
     acc[64] = 0;
     acc[128] = 0;
     acc[192] = 0;
-    mj_decode_span(cx, p, k, c, end, nb, acc, 64);
+    mj_run_span(cx, L, end, nb, acc, 64);
     LaneRec r;
-    r.p = p;
-    r.kc = (c << 8) | k;
+    r.p = L.p;
+    r.kc = (L.c << 8) | L.k;
     r.nb = nb;
     r.d0 = acc[0];
     r.d1 = acc[64];
@@ -128,16 +137,28 @@ __device__ __forceinline__ LaneRec decode_nowrite(const MjScanCtx &cx, uint32_t 
     return r;
 }
 
-__device__ __forceinline__ LaneRec shfl_up_rec(const LaneRec &r, int d) {
-    LaneRec o;
-    o.p = __shfl_up(r.p, d, 64);
-    o.kc = __shfl_up(r.kc, d, 64);
-    o.nb = __shfl_up(r.nb, d, 64);
-    o.d0 = __shfl_up(r.d0, d, 64);
-    o.d1 = __shfl_up(r.d1, d, 64);
-    o.d2 = __shfl_up(r.d2, d, 64);
-    o.d3 = __shfl_up(r.d3, d, 64);
-    return o;
+/* the same from a bare state */
+__device__ __forceinline__ LaneRec decode_nowrite(const MjScanCtx &cx, uint32_t p, uint32_t kc, uint32_t end, int32_t *acc) {
+    if (p >= end) {
+        const LaneRec r = {p, kc, 0, 0, 0, 0, 0};
+        return r;
+    }
+    MjLane L;
+    mj_lane_init(cx, L, p, kc & 0xFFu, kc >> 8);
+    return run_nowrite(cx, L, end, acc);
+}
+
+__device__ __forceinline__ void store_rec(MjSubRec *dst, const LaneRec &r) {
+    MjSubRec o;
+    o.exit.p = r.p;
+    o.exit.kc = r.kc;
+    o.nb = r.nb;
+    o.dcsum[0] = r.d0;
+    o.dcsum[1] = r.d1;
+    o.dcsum[2] = r.d2;
+    o.dcsum[3] = r.d3;
+    o.pad_ = 0;
+    *dst = o;
 }
 
 /* exclusive prefix over the lanes of a wave for the five counters of a record */
@@ -165,77 +186,133 @@ __device__ __forceinline__ void wave_excl_scan5(uint32_t &nb, int32_t &d0, int32
 }
 
 /* ------------------------------------------------------------------------ */
-/* kernel 1: per sequence -- cold decode, lock-step synchronisation rounds, */
-/* and, for single-sequence intervals, prefix sums + the writing pass       */
+/* kernel 1: cold decode + synchronisation rounds over a workgroup's        */
+/* sequences                                                                */
 /* ------------------------------------------------------------------------ */
-__global__ __launch_bounds__(TPB) void mj_k_entropy_sync(MjDeviceBatch b) {
+struct SeqGeo {           /* one sequence of the workgroup, in LDS */
+    uint32_t b0, b1;      /* bit range of its interval */
+    uint32_t nsub;        /* subsequences in the interval */
+    uint32_t first;       /* the sequence's first subsequence within the interval */
+    uint32_t n;           /* subsequences in the sequence (0: no such sequence) */
+    uint32_t rec_base;    /* index of its first record */
+    uint32_t pad_[2];
+};
+
+/* A decoder that has to go on: (entry bit position, packed rest).  Packed: bits 0-11
+ * (slot << 8) | zigzag index, bits 12-14 sequence within the workgroup, bits 16-25 the
+ * subsequence (within the sequence) to decode next. */
+__device__ __forceinline__ void push_task(bool have, uint32_t p, uint32_t packed, uint2 *queue, uint32_t *count) {
+    const unsigned long long mask = __ballot(have);
+    if (mask == 0) return;
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(count, (uint32_t) __popcll(mask));
+    base = __shfl(base, 0, 64);
+    if (have) queue[base + __popcll(mask & ((1ull << lane) - 1ull))] = make_uint2(p, packed);
+}
+
+__global__ __launch_bounds__(SYNC_TPB) void mj_k_entropy_sync(MjDeviceBatch b) {
     const uint32_t ii = b.wg_img[blockIdx.x];
     const MjImageDev &im = b.img[ii];
     const uint32_t n_seq = b.dyn[ii].n_seq;
-    const uint32_t seq0 = (blockIdx.x - im.wg_first) * WAVES;
+    const uint32_t seq0 = (blockIdx.x - im.wg_first) * SYNC_WAVES;
     if (seq0 >= n_seq) return;
+
+    /* dynamic LDS: [tables][slots][DC accumulators][sequence geometry][3 queue counters][2 queues] */
+    SeqGeo *s_geo = reinterpret_cast<SeqGeo *>(lds_after_dc(b, SYNC_WAVES));
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_geo + SYNC_WAVES);
+    uint2 *s_queue = reinterpret_cast<uint2 *>(s_cnt + 4);
+
+    const uint32_t S = im.sub_bits, G = im.lane_subs, SQ = MJ_SEQ_LANES * G;
     load_tables(b, im);
+    if (threadIdx.x < SYNC_WAVES) {
+        SeqGeo sg = {0, 0, 0, 0, 0, 0, {0, 0}};
+        const uint32_t seq = seq0 + threadIdx.x;
+        if (seq < n_seq) {
+            const uint32_t iv = b.seq_ivl[im.seq_off + seq];
+            const Geo g = interval_geo(b.ivl_start + im.ivl_off, iv, S, SQ);
+            sg.b0 = g.b0;
+            sg.b1 = g.b1;
+            sg.nsub = g.nsub;
+            sg.first = b.seq_sub[im.seq_off + seq];
+            sg.n = min(g.nsub - sg.first, SQ);
+            sg.rec_base = im.rec_off + seq * SQ;
+        }
+        s_geo[threadIdx.x] = sg;
+    }
+    if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
     __syncthreads();
+
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t seq = seq0 + wave;
-    if (seq >= n_seq) return;
-
-    const uint32_t S = im.sub_bits;
-    const uint32_t iv = b.seq_ivl[im.seq_off + seq];
-    const uint32_t first = b.seq_sub[im.seq_off + seq];
-    const Geo g = interval_geo(b.ivl_start + im.ivl_off, iv, S);
-    const uint32_t n = min(g.nsub - first, (uint32_t) MJ_SEQ_SUBS);
     const MjScanCtx cx = make_ctx(b, im);
-
-    const bool valid = lane < n;
-    const uint32_t j = first + lane;
-    const uint32_t start = g.b0 + j * S;
-    const uint32_t end_own = sub_end(g, j, S);
-
-    /* round 0: cold start at the subsequence boundary (exact for the interval's first) */
-    LaneRec rec = {start, 0, 0, 0, 0, 0, 0};
     int32_t *acc = lds_dc(b) + wave * 64 * MJ_MAX_COMP + lane;
-    if (valid) rec = decode_nowrite(cx, start, 0, end_own, acc);
-    uint32_t carry_p = rec.p, carry_kc = rec.kc;
-    bool active = valid && (lane + 1 < n);
-    uint32_t rounds = 0;
-    for (uint32_t r = 1; r < n; r++) {
-        if (!__any(active) || (b.dbg & 2u)) break;
-        rounds++;
-        LaneRec out = rec;
-        if (active) out = decode_nowrite(cx, carry_p, carry_kc, sub_end(g, j + r, S), acc);
-        /* lane m = l + r takes what lane l produced for subsequence m */
-        const LaneRec in = shfl_up_rec(out, (int) r);
-        const int in_active = __shfl_up((int) active, (int) r, 64);
-        int synced = 0;
-        if (lane >= r && in_active) {
-            synced = (in.p == rec.p && in.kc == rec.kc);
-            rec = in;
+
+    /* cold pass: the lane's subsequences back to back from a cold state at its first
+     * (exact for the first lane of an interval), one record after each */
+    {
+        const SeqGeo g = s_geo[wave];
+        const uint32_t u0 = lane * G;
+        bool more = false;
+        uint32_t tp = 0, tkc = 0;
+        if (u0 < g.n) {
+            const uint32_t j0 = g.first + u0;
+            MjLane L;
+            mj_lane_init(cx, L, g.b0 + j0 * S, 0, 0);
+            for (uint32_t q = 0; q < G; q++) {
+                if (u0 + q < g.n) {
+                    const LaneRec r = run_nowrite(cx, L, sub_end(g.b0, g.b1, g.nsub, j0 + q, S), acc);
+                    store_rec(b.rec + g.rec_base + u0 + q, r);
+                }
+            }
+            more = (u0 + G < g.n);
+            tp = L.p;
+            tkc = (L.c << 8) | L.k;
         }
-        const int told = __shfl_down(synced, (int) r, 64);
-        if (active) {
-            carry_p = out.p;
-            carry_kc = out.kc;
-            if (told || lane + r + 1 >= n) active = false;
-        }
+        push_task(more, tp, tkc | (wave << 12) | ((u0 + G) << 16), s_queue, &s_cnt[0]);
     }
-    if (lane == 0) {
+    __syncthreads();
+
+    /* rounds: every queued decoder decodes one more subsequence, replaces its record and
+     * goes on while the state it reached differs from the one recorded there before */
+    uint32_t rounds = 0, tasks = 0;
+    const uint32_t max_rounds = (b.dbg >> 8) & 0xFFu;   /* timing experiments only */
+    uint32_t ci = 0;                         /* counter of this round; next is ci + 1, the one to clear ci + 2 (mod 3) */
+    for (;;) {
+        const uint32_t total = s_cnt[ci];
+        if (total == 0 || (b.dbg & 2u) || (max_rounds && rounds >= max_rounds)) break;
+        const uint32_t cn = (ci == 2) ? 0 : ci + 1, cz = (cn == 2) ? 0 : cn + 1;
+        if (threadIdx.x == 0) s_cnt[cz] = 0;
+        const uint2 *qin = s_queue + (rounds & 1u) * SYNC_TPB;
+        uint2 *qout = s_queue + ((rounds + 1) & 1u) * SYNC_TPB;
+        rounds++;
+        tasks += total;
+        if (wave * 64 < total) {
+            bool more = false;
+            uint32_t tp = 0, packed = 0;
+            if (threadIdx.x < total) {
+                const uint2 tk = qin[threadIdx.x];
+                const uint32_t sw = (tk.y >> 12) & 7u, u = tk.y >> 16;
+                const SeqGeo g = s_geo[sw];
+                MjSubRec *dst = b.rec + g.rec_base + u;
+                const MjState old = dst->exit;
+                const LaneRec r = decode_nowrite(cx, tk.x, tk.y & 0xFFFu, sub_end(g.b0, g.b1, g.nsub, g.first + u, S), acc);
+                store_rec(dst, r);
+                more = !(r.p == old.p && r.kc == old.kc) && (u + 1 < g.n);
+                tp = r.p;
+                packed = r.kc | (sw << 12) | ((u + 1) << 16);
+            }
+            push_task(more, tp, packed, qout, &s_cnt[cn]);
+        }
+        __syncthreads();
+        ci = cn;
+    }
+    if (threadIdx.x == 0) {
         atomicAdd(&b.stats[MJ_ST_ROUNDS], (unsigned long long) rounds);
         atomicMax(&b.stats[MJ_ST_MAXROUNDS], (unsigned long long) rounds);
+        atomicAdd(&b.stats[MJ_ST_TASKS], (unsigned long long) tasks);
+        atomicAdd(&b.stats[MJ_ST_WGS], 1ull);
     }
-
-    /* one record per subsequence for the fix-up / writing kernels */
-    MjSubRec o;
-    o.exit.p = rec.p;
-    o.exit.kc = rec.kc;
-    o.nb = valid ? rec.nb : 0;
-    o.dcsum[0] = valid ? rec.d0 : 0;
-    o.dcsum[1] = valid ? rec.d1 : 0;
-    o.dcsum[2] = valid ? rec.d2 : 0;
-    o.dcsum[3] = valid ? rec.d3 : 0;
-    o.pad_ = 0;
-    b.rec[(uint64_t) (im.seq_off + seq) * MJ_SEQ_SUBS + lane] = o;
 }
 
 /* ------------------------------------------------------------------------ */
@@ -251,14 +328,14 @@ __global__ __launch_bounds__(FIX_TPB) void mj_k_entropy_fix(MjDeviceBatch b) {
     const uint2 mi = b.multi[blockIdx.x];
     const MjImageDev &im = b.img[mi.x];
     const uint32_t iv = mi.y;
-    const uint32_t S = im.sub_bits;
-    const Geo g = interval_geo(b.ivl_start + im.ivl_off, iv, S);
+    const uint32_t S = im.sub_bits, SQ = MJ_SEQ_LANES * im.lane_subs;
+    const Geo g = interval_geo(b.ivl_start + im.ivl_off, iv, S, SQ);
     const uint32_t seq_first = im.seq_off + b.ivl_seq[im.ivl_off + iv]; /* global slot of the interval's first sequence */
     load_tables(b, im);
     __syncthreads();
     const MjScanCtx cx = make_ctx(b, im);
     int32_t *fix_acc = lds_dc(b) + (threadIdx.x >> 6) * 64 * MJ_MAX_COMP + (threadIdx.x & 63);
-    MjSubRec *rec = b.rec + (uint64_t) seq_first * MJ_SEQ_SUBS;
+    MjSubRec *rec = b.rec + im.rec_off + (uint64_t) b.ivl_seq[im.ivl_off + iv] * SQ;
 
     /* Boundary q (1 <= q < nseq): the decoder that leaves sequence q-1 continues
      * into sequence q, overwriting its records, until it meets a recorded exit
@@ -268,7 +345,7 @@ __global__ __launch_bounds__(FIX_TPB) void mj_k_entropy_fix(MjDeviceBatch b) {
         if (threadIdx.x == 0) s_changed = 0;
         __syncthreads();
         for (uint32_t q = 1 + threadIdx.x; q < g.nseq; q += FIX_TPB) {
-            const MjState e = rec[(uint64_t) q * MJ_SEQ_SUBS - 1].exit;
+            const MjState e = rec[(uint64_t) q * SQ - 1].exit;
             const MjState seen = b.seq_seen[seq_first + q];
             const bool redo = (iters == 0) || e.p != seen.p || e.kc != seen.kc;
             b.seq_flag[seq_first + q] = redo ? 1u : 0u;
@@ -284,22 +361,13 @@ __global__ __launch_bounds__(FIX_TPB) void mj_k_entropy_fix(MjDeviceBatch b) {
             if (!b.seq_flag[seq_first + q]) continue;
             const MjState e = b.seq_seen[seq_first + q];
             uint32_t p = e.p, kc = e.kc;
-            const uint32_t first = q * MJ_SEQ_SUBS;
-            const uint32_t n = min(g.nsub - first, (uint32_t) MJ_SEQ_SUBS);
+            const uint32_t first = q * SQ;
+            const uint32_t n = min(g.nsub - first, (uint32_t) SQ);
             for (uint32_t l = 0; l < n; l++) {
-                const LaneRec o = decode_nowrite(cx, p, kc, sub_end(g, first + l, S), fix_acc);
+                const LaneRec o = decode_nowrite(cx, p, kc, sub_end(g.b0, g.b1, g.nsub, first + l, S), fix_acc);
                 MjSubRec *dst = rec + (uint64_t) first + l;
                 const MjState old = dst->exit;
-                MjSubRec w;
-                w.exit.p = o.p;
-                w.exit.kc = o.kc;
-                w.nb = o.nb;
-                w.dcsum[0] = o.d0;
-                w.dcsum[1] = o.d1;
-                w.dcsum[2] = o.d2;
-                w.dcsum[3] = o.d3;
-                w.pad_ = 0;
-                *dst = w;
+                store_rec(dst, o);
                 p = o.p;
                 kc = o.kc;
                 if (old.p == o.p && old.kc == o.kc) break;
@@ -319,8 +387,8 @@ __global__ __launch_bounds__(FIX_TPB) void mj_k_entropy_fix(MjDeviceBatch b) {
     uint32_t tnb = 0;
     int32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
     for (uint32_t q = q_lo; q < q_hi; q++) {
-        const uint32_t first = q * MJ_SEQ_SUBS;
-        const uint32_t n = min(g.nsub - first, (uint32_t) MJ_SEQ_SUBS);
+        const uint32_t first = q * SQ;
+        const uint32_t n = min(g.nsub - first, (uint32_t) SQ);
         for (uint32_t l = 0; l < n; l++) {
             const MjSubRec &r = rec[(uint64_t) first + l];
             tnb += r.nb;
@@ -357,7 +425,7 @@ __global__ __launch_bounds__(FIX_TPB) void mj_k_entropy_fix(MjDeviceBatch b) {
             se.entry.p = g.b0;
             se.entry.kc = 0;
         } else {
-            se.entry = rec[(uint64_t) q * MJ_SEQ_SUBS - 1].exit;
+            se.entry = rec[(uint64_t) q * SQ - 1].exit;
         }
         se.blk = blk_base + anb;
         se.pred[0] = a0;
@@ -366,8 +434,8 @@ __global__ __launch_bounds__(FIX_TPB) void mj_k_entropy_fix(MjDeviceBatch b) {
         se.pred[3] = a3;
         se.pad_ = 0;
         b.seq_entry[seq_first + q] = se;
-        const uint32_t first = q * MJ_SEQ_SUBS;
-        const uint32_t n = min(g.nsub - first, (uint32_t) MJ_SEQ_SUBS);
+        const uint32_t first = q * SQ;
+        const uint32_t n = min(g.nsub - first, (uint32_t) SQ);
         for (uint32_t l = 0; l < n; l++) {
             const MjSubRec &r = rec[(uint64_t) first + l];
             anb += r.nb;
@@ -385,15 +453,17 @@ __global__ __launch_bounds__(FIX_TPB) void mj_k_entropy_fix(MjDeviceBatch b) {
 constexpr int BLK_STRIDE = 128;   /* bytes per lane block buffer (unpadded: LDS capacity decides the occupancy here) */
 
 __global__ __launch_bounds__(TPB) void mj_k_entropy_write(MjDeviceBatch b) {
-    /* dynamic LDS: [tables][slots][block buffers: TPB x 144 B][flush lists: TPB x (4 + 4) B] */
-    unsigned char *s_blk = lds_after_dc(b);
+    /* dynamic LDS: [tables][slots][DC accumulators][block buffers: TPB x 128 B][flush lists: TPB x (4 + 4) B] */
+    unsigned char *s_blk = lds_after_dc(b, WAVES);
     uint32_t *s_list_blk = reinterpret_cast<uint32_t *>(s_blk + TPB * BLK_STRIDE);
     uint32_t *s_list_lane = s_list_blk + TPB;
 
-    const uint32_t ii = b.wg_img[blockIdx.x];
+    /* two workgroups of WAVES sequences per group of MJ_WG_SEQS */
+    const uint32_t grp = blockIdx.x / (MJ_WG_SEQS / WAVES), part = blockIdx.x % (MJ_WG_SEQS / WAVES);
+    const uint32_t ii = b.wg_img[grp];
     const MjImageDev &im = b.img[ii];
     const uint32_t n_seq = b.dyn[ii].n_seq;
-    const uint32_t seq0 = (blockIdx.x - im.wg_first) * WAVES;
+    const uint32_t seq0 = (grp - im.wg_first) * MJ_WG_SEQS + part * WAVES;
     if (seq0 >= n_seq) return;
     load_tables(b, im);
     {   /* zero the block buffers */
@@ -406,14 +476,29 @@ __global__ __launch_bounds__(TPB) void mj_k_entropy_write(MjDeviceBatch b) {
     const uint32_t seq = seq0 + wave;
     if (seq >= n_seq) return;
 
-    const uint32_t S = im.sub_bits;
+    const uint32_t S = im.sub_bits, G = im.lane_subs, SQ = MJ_SEQ_LANES * G;
     const uint32_t iv = b.seq_ivl[im.seq_off + seq];
     const uint32_t first = b.seq_sub[im.seq_off + seq];
-    const Geo g = interval_geo(b.ivl_start + im.ivl_off, iv, S);
-    const uint32_t n = min(g.nsub - first, (uint32_t) MJ_SEQ_SUBS);
+    const Geo g = interval_geo(b.ivl_start + im.ivl_off, iv, S, SQ);
+    const uint32_t n = min(g.nsub - first, SQ);
     const MjScanCtx cx = make_ctx(b, im);
-    const bool valid = lane < n;
-    const MjSubRec r = b.rec[(uint64_t) (im.seq_off + seq) * MJ_SEQ_SUBS + lane];
+    /* the lane's subsequences: u0 .. u0 + cnt - 1 of the sequence */
+    const uint32_t u0 = lane * G;
+    const bool valid = u0 < n;
+    const uint32_t cnt = valid ? min(G, n - u0) : 0u;
+    const MjSubRec *recs = b.rec + im.rec_off + (uint64_t) seq * SQ;
+    uint32_t nb = 0, last_p = 0, last_kc = 0;
+    int32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+    for (uint32_t q = 0; q < cnt; q++) {
+        const MjSubRec r = recs[u0 + q];
+        nb += r.nb;
+        d0 += r.dcsum[0];
+        d1 += r.dcsum[1];
+        d2 += r.dcsum[2];
+        d3 += r.dcsum[3];
+        last_p = r.exit.p;
+        last_kc = r.exit.kc;
+    }
 
     /* where the sequence starts: the interval start, or what the fix-up computed */
     const uint32_t n_blocks = im.n_mcu * im.bpm;
@@ -426,18 +511,16 @@ __global__ __launch_bounds__(TPB) void mj_k_entropy_write(MjDeviceBatch b) {
     se.pred[0] = se.pred[1] = se.pred[2] = se.pred[3] = 0;
     if (g.nseq > 1) se = b.seq_entry[im.seq_off + seq];
 
-    uint32_t p = __shfl_up(r.exit.p, 1, 64), kc = __shfl_up(r.exit.kc, 1, 64);
+    /* entry state: where the lane before stopped */
+    uint32_t p = __shfl_up(last_p, 1, 64), kc = __shfl_up(last_kc, 1, 64);
     if (lane == 0) {
         p = se.entry.p;
         kc = se.entry.kc;
     }
-    uint32_t nb = valid ? r.nb : 0;
-    int32_t d0 = valid ? r.dcsum[0] : 0, d1 = valid ? r.dcsum[1] : 0, d2 = valid ? r.dcsum[2] : 0,
-            d3 = valid ? r.dcsum[3] : 0;
     const uint32_t own_nb = nb;
     wave_excl_scan5(nb, d0, d1, d2, d3);
     /* every block of the interval must be accounted for by its last sequence */
-    if (first + n == g.nsub && lane == n - 1 && se.blk + nb + own_nb < blk_end) atomicOr(&b.dyn[ii].status, 1u);
+    if (first + n == g.nsub && valid && u0 + cnt == n && se.blk + nb + own_nb < blk_end) atomicOr(&b.dyn[ii].status, 1u);
     if (b.dbg & 1u) return;
 
     uint32_t k = kc & 0xFFu, c = kc >> 8;
@@ -448,7 +531,7 @@ __global__ __launch_bounds__(TPB) void mj_k_entropy_write(MjDeviceBatch b) {
     acc[128] = d2 + se.pred[2];
     acc[192] = d3 + se.pred[3];
     bool skip = (k != 0);
-    const uint32_t end = sub_end(g, first + lane, S);
+    const uint32_t end = sub_end(g.b0, g.b1, g.nsub, first + u0 + (cnt ? cnt - 1 : 0), S);
     int16_t *blkbuf = reinterpret_cast<int16_t *>(s_blk + (wave * 64 + lane) * BLK_STRIDE);
     uint32_t *list_blk = s_list_blk + wave * 64, *list_lane = s_list_lane + wave * 64;
     const unsigned char *wave_blk = s_blk + wave * 64 * BLK_STRIDE;
@@ -524,12 +607,14 @@ __global__ __launch_bounds__(TPB) void mj_k_entropy_serial(MjDeviceBatch b) {
 }  // namespace
 
 static size_t table_lds(const MjDeviceBatch &b, uint32_t waves) {
-    return (size_t) b.max_ntab * sizeof(MjHuffDev) + 16 * sizeof(uint32_t) + (size_t) waves * 64 * MJ_MAX_COMP * sizeof(int32_t);
+    return (size_t) b.max_ntab * sizeof(MjHuffDev) + 16 * sizeof(uint32_t) + (size_t) waves * DC_WAVE_BYTES;
 }
 
 hipError_t mj_launch_entropy(const MjDeviceBatch &b, hipStream_t s) {
     if (b.n_entropy_wg == 0) return hipSuccess;
-    hipLaunchKernelGGL(mj_k_entropy_sync, dim3(b.n_entropy_wg), dim3(TPB), table_lds(b, WAVES), s, b);
+    static const size_t pad = getenv("MJ_TUNE_LDS_PAD") ? (size_t) atol(getenv("MJ_TUNE_LDS_PAD")) : 0;   /* occupancy experiments */
+    const size_t lds = table_lds(b, SYNC_WAVES) + SYNC_WAVES * sizeof(SeqGeo) + 4 * sizeof(uint32_t) + 2 * SYNC_TPB * sizeof(uint2) + pad;
+    hipLaunchKernelGGL(mj_k_entropy_sync, dim3(b.n_entropy_wg), dim3(SYNC_TPB), lds, s, b);
     return hipGetLastError();
 }
 
@@ -542,7 +627,7 @@ hipError_t mj_launch_entropy_fix(const MjDeviceBatch &b, hipStream_t s) {
 hipError_t mj_launch_entropy_write(const MjDeviceBatch &b, hipStream_t s) {
     if (b.n_entropy_wg == 0) return hipSuccess;
     const size_t lds = table_lds(b, WAVES) + (size_t) TPB * BLK_STRIDE + (size_t) TPB * 8;
-    hipLaunchKernelGGL(mj_k_entropy_write, dim3(b.n_entropy_wg), dim3(TPB), lds, s, b);
+    hipLaunchKernelGGL(mj_k_entropy_write, dim3(b.n_entropy_wg * (MJ_WG_SEQS / WAVES)), dim3(TPB), lds, s, b);
     return hipGetLastError();
 }
 

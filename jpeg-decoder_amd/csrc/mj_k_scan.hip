@@ -207,10 +207,10 @@ __global__ __launch_bounds__(TPB) void mj_k_scan_write(MjDeviceBatch b) {
 #pragma unroll
     for (int i = 0; i < 16; i++) {
         const uint32_t c = (cls >> (2 * i)) & 3u;
-        if (pos + i >= term) break;
-        if (c == MJ_B_KEEP) {
+        const bool live = pos + i < term;
+        if (live && c == MJ_B_KEEP) {
             dst[out++] = (uint8_t) ((w[i >> 2] >> (8 * (i & 3))) & 0xFFu);
-        } else if (c == MJ_B_RST) {
+        } else if (live && c == MJ_B_RST) {
             ridx++;
             if (ridx < im.n_ivl) ivl[ridx] = out; /* interval ridx starts at the next surviving byte */
         }
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(TPB) void mj_k_layout(MjDeviceBatch b) {
     uint32_t *ivl_seq = b.ivl_seq + im.ivl_off;
     const uint32_t cmp_len = dy.cmp_len;
     const uint32_t n_rst = dy.n_rst;
-    const uint32_t S = im.sub_bits;
+    const uint32_t S = im.sub_bits, SQ = MJ_SEQ_LANES * im.lane_subs;
     /* interval 0 starts at 0; intervals whose RSTn never came are empty */
     for (uint32_t k = threadIdx.x; k <= im.n_ivl; k += TPB) {
         if (k == 0) ivl[0] = 0;
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(TPB) void mj_k_layout(MjDeviceBatch b) {
             const uint32_t bits = (e > a) ? (e - a) * 8u : 0u;
             nsub = (bits + S - 1) / S;
             if (nsub == 0) nsub = 1;
-            nseq = (nsub + MJ_SEQ_SUBS - 1) / MJ_SEQ_SUBS;
+            nseq = (nsub + SQ - 1) / SQ;
         }
         uint32_t tot;
         const uint32_t first = carry + block_excl_scan(nseq, s_w, &tot);
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(TPB) void mj_k_layout(MjDeviceBatch b) {
             for (uint32_t q = 0; q < nseq; q++) {
                 if (first + q < im.seq_cap) {
                     b.seq_ivl[im.seq_off + first + q] = iv;
-                    b.seq_sub[im.seq_off + first + q] = q * MJ_SEQ_SUBS;
+                    b.seq_sub[im.seq_off + first + q] = q * SQ;
                 }
             }
             if (nseq > 1) {

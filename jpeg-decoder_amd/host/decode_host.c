@@ -97,7 +97,7 @@ Image *allocate_img(FrameHeader *fh) {
         if (c->hsf == 0 || c->vsf == 0) goto fail;
         /* each plane is padded to whole MCUs */
         size_t w = pad_to_mcu(c->x, 8 * c->hsf), h = pad_to_mcu(c->y, 8 * c->vsf);
-        img->buf[i] = (uint8_t *) calloc(w * h ? w * h : 1, 1);
+        img->buf[i] = (uint8_t *) calloc((w && h) ? w * h : 1, 1);
         if (!img->buf[i]) goto fail;
         img->width[i] = (int) w;
         img->n_du = (uint8_t) (i + 1);

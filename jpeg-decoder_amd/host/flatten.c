@@ -178,18 +178,39 @@ static uint32_t pad_up(uint32_t v, uint32_t unit) {
     return (v % unit) ? v + unit - (v % unit) : v;
 }
 
-uint32_t mj_choose_sub_bits(uint64_t raw_len, uint32_t n_ivl) {
+static uint32_t env_u32(const char *name) {
+    const char *e = getenv(name);
+    return (e && *e) ? (uint32_t) strtoul(e, NULL, 0) : 0u;
+}
+
+void mj_choose_split(uint64_t raw_len, uint32_t n_ivl, uint32_t *sub_bits, uint32_t *lane_subs) {
     uint64_t bits = raw_len * 8;
     uint64_t avg = bits / (n_ivl ? n_ivl : 1);
-    if (avg > (uint64_t) MJ_SEQ_SUBS * 4096) {
-        return 1024; /* long intervals: many sequences per interval, short subsequences */
+    uint64_t lane_bits;
+    uint32_t g;
+    if (avg > (uint64_t) MJ_SEQ_LANES * 4096) {
+        /* long intervals: many sequences per interval, short lanes */
+        lane_bits = 1024;
+        g = 1;
+    } else {
+        /* one wavefront per interval with a little headroom for uneven intervals */
+        lane_bits = (avg + avg / 16 + MJ_SEQ_LANES - 1) / MJ_SEQ_LANES;
+        if (lane_bits < 128) lane_bits = 128;
+        if (lane_bits > 4096) lane_bits = 4096;
+        /* records every ~512 bits: a decoder that continues past its own lane stops at the
+         * first record it agrees with, so finer records mean less re-decoding */
+        g = lane_bits >= 1024 ? 4 : lane_bits >= 512 ? 2 : 1;
     }
-    /* one wavefront per interval with a little headroom for uneven intervals */
-    uint64_t s = (avg + avg / 16 + MJ_SEQ_SUBS - 1) / MJ_SEQ_SUBS;
+    /* tuning overrides (experiments only) */
+    uint32_t t = env_u32("MJ_TUNE_LANE_SUBS");
+    if (t >= 1 && t <= MJ_MAX_LANE_SUBS) g = t;
+    uint64_t s = (lane_bits + g - 1) / g;
+    t = env_u32("MJ_TUNE_SUB_BITS");
+    if (t) s = t;
     s = (s + 31) / 32 * 32;
-    if (s < 128) s = 128;
-    if (s > 4096) s = 4096;
-    return (uint32_t) s;
+    if (s > 32768) s = 32768;
+    *sub_bits = (uint32_t) s;
+    *lane_subs = g;
 }
 
 int mj_flatten_image(const MjParsed *p, size_t file_len, MjImageDev *img, MjHuffSet *set, const char **why) {
@@ -292,7 +313,7 @@ int mj_flatten_image(const MjParsed *p, size_t file_len, MjImageDev *img, MjHuff
     img->ri = p->ri ? p->ri : img->n_mcu;
     img->n_ivl = (img->n_mcu + img->ri - 1) / img->ri;
     img->raw_len = file_len - p->ent_pos;
-    img->sub_bits = mj_choose_sub_bits(img->raw_len, img->n_ivl);
+    mj_choose_split(img->raw_len, img->n_ivl, &img->sub_bits, &img->lane_subs);
     img->pitch = (3 * img->X + 3u) & ~3u; /* rows start 4-byte aligned */
     return 0;
 }

@@ -38,9 +38,9 @@ void mj_flatten_huff(const HuffTable *ht, MjHuffDev *out, MjHuffWalk *walk);
  * image.  Batch placement fields are left zero.  0 / -1. */
 int mj_flatten_image(const MjParsed *p, size_t file_len, MjImageDev *img, MjHuffSet *set, const char **why);
 
-/* Subsequence length (bits, multiple of 32) for an entropy segment of raw_len
- * bytes split into n_ivl restart intervals. */
-uint32_t mj_choose_sub_bits(uint64_t raw_len, uint32_t n_ivl);
+/* How an entropy segment of raw_len bytes in n_ivl restart intervals is cut up:
+ * subsequence length (bits, multiple of 32) and subsequences per lane. */
+void mj_choose_split(uint64_t raw_len, uint32_t n_ivl, uint32_t *sub_bits, uint32_t *lane_subs);
 
 #ifdef __cplusplus
 }

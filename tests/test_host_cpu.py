@@ -56,25 +56,26 @@ def test_dropin_entry_fails_loudly_without_gpu():
 
 
 @pytest.mark.parametrize("name", ALL_FIXTURES)
-@pytest.mark.parametrize("sub_bits", [0, 32, 96, 1024])
-def test_entropy_algorithm_emulated(name, sub_bits):
+@pytest.mark.parametrize("sub_bits,lane_subs", [(0, 0), (32, 1), (32, 3), (96, 2), (64, 8), (1024, 1), (512, 4)])
+def test_entropy_algorithm_emulated(name, sub_bits, lane_subs):
     """Host parsers + table flattening + scan/unstuff rules + subsequence
     synchronisation, prefix sums and write pass (the kernels' algorithm run lane by
     lane on the CPU) against the reference's coefficient blocks."""
     emu = J.Emu()
     data, gold = load_fixture(name)
     nref = gold["coefs"].shape[0]
-    got, st = emu.decode_coefs(data, nref + 16, sub_bits)
+    got, st = emu.decode_coefs(data, nref + 16, sub_bits, lane_subs)
     assert got.shape[0] >= nref
     assert np.array_equal(got[:nref], gold["coefs"])
     if sub_bits:
         assert st["sub_bits"] == (sub_bits + 31) // 32 * 32
+        assert st["lane_subs"] == lane_subs
 
 
 def test_emulation_exercises_the_cross_sequence_path():
     emu = J.Emu()
     data, gold = load_fixture("C1_c420_q85_512x512")
-    got, st = emu.decode_coefs(data, gold["coefs"].shape[0], 128)
+    got, st = emu.decode_coefs(data, gold["coefs"].shape[0], 128, 1)
     assert st["multi_seq_intervals"] == 1 and st["sequences"] > 8 and st["fix_iterations"] >= 1
     assert np.array_equal(got, gold["coefs"])
 
@@ -88,7 +89,7 @@ def test_synthetic_generator_is_decodable_and_deterministic(oracle):
         d = oracle.decode(a)
         assert (d.X, d.Y, d.ncs) == (96, 64, 3)
         assert np.abs(d.rgb.astype(int) - img).mean() < 12.0
-        got, _ = J.Emu().decode_coefs(a, d.coefs.shape[0], 64)
+        got, _ = J.Emu().decode_coefs(a, d.coefs.shape[0], 64, 2)
         assert np.array_equal(got, d.coefs)
     g = J.synth.encode_jpeg(img[..., 1].copy(), quality=75, restart_interval=4)
     d = oracle.decode(g)
