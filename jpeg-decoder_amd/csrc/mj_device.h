@@ -22,8 +22,27 @@
 #define MJ_SUB_BITS (16 - MJ_LUT_BITS)
 #define MJ_SUB_SIZE (1 << MJ_SUB_BITS)
 #define MJ_SUB_MAX 8           /* second-level tables per Huffman table */
-#define MJ_LUT_LONG 0xF000u    /* first-level entry: code longer than MJ_LUT_BITS, low byte = second-level table */
-#define MJ_LUT_WALK 0xE000u    /* first-level entry: longer code that found no second-level table: canonical walk */
+/* Lookup entry, 16 bits, what one code means for the decoder:
+ *   bits 15-11  code length 1..16
+ *   bits 10-7   size: value bits that follow the code
+ *   bits 6-0    how far the zigzag index moves: run + 1 for an AC (run, size) symbol,
+ *               64 for end of block, 1 for a DC category
+ * A first-level entry with length 0 is not a code: */
+#define MJ_E_LEN(e) ((uint32_t) (e) >> 11)
+#define MJ_LUT_LONG 0x0400u    /* code longer than MJ_LUT_BITS; low bits = second-level table */
+#define MJ_LUT_WALK 0x0200u    /* longer code that found no second-level table: canonical walk */
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define MJ_DEV_INLINE static inline __host__ __device__
+#else
+#define MJ_DEV_INLINE static inline
+#endif
+
+MJ_DEV_INLINE uint32_t mj_lut_entry(uint32_t len, uint32_t sym, int is_ac) {
+    const uint32_t kinc = !is_ac ? 1u : (sym == 0 ? 64u : (sym >> 4) + 1u);
+    return (len << 11) | ((sym & 15u) << 7) | kinc;
+}
 
 /* One Huffman table, flattened from the reference's HuffTable (huff_table.h:9-14):
  * a direct lookup on the next MJ_LUT_BITS bits for short codes; for longer codes a
@@ -31,8 +50,8 @@
  * entry; and the canonical ranges (decode.c:674-681 compares against max_codes per
  * length) as the fallback for tables that need more second-level tables than fit. */
 typedef struct {
-    uint16_t lut[MJ_LUT_SIZE]; /* (length << 8) | symbol; MJ_LUT_LONG | n; MJ_LUT_WALK; 0 = no code has this prefix */
-    uint16_t sub[MJ_SUB_MAX][MJ_SUB_SIZE]; /* (length << 8) | symbol, 0 = no such code */
+    uint16_t lut[MJ_LUT_SIZE]; /* entry; MJ_LUT_LONG | n; MJ_LUT_WALK */
+    uint16_t sub[MJ_SUB_MAX][MJ_SUB_SIZE]; /* entry */
 } MjHuffDev;                   /* the part the kernels keep in LDS */
 
 typedef struct {

@@ -118,6 +118,7 @@ int64_t mj_emu_decode_coefs(const uint8_t *file, size_t len, int16_t *coefs, int
     cx.stream = (const uint32_t *) L.cmp.data();
     uint32_t slots[MJ_MAX_BPM + 2];
     for (uint32_t i = 0; i < img.bpm; i++) slots[i] = mj_slot_pack(img.blk_comp[i], img.blk_dc[i], img.blk_ac[i]);
+    slots[img.bpm] = slots[0];
     cx.tabs = (const unsigned char *) set->tab;
     cx.walk = set->walk;
     cx.slots = slots;

@@ -15,20 +15,23 @@
 
 #include <stdint.h>
 
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#endif
+
 #include "mj_device.h"
 
 #if defined(__HIPCC__)
-#include <hip/hip_runtime.h>
 #define MJ_HD __host__ __device__ __forceinline__
 #else
 #define MJ_HD static inline
 #endif
 
-/* Per block slot of the MCU: LDS/host byte offsets of its DC and AC tables and its
- * component, packed: bits 0-1 component, bits 2-15 DC table offset / 4, bits 16-31
- * AC table offset / 4 (tables are 16-byte multiples). */
+/* Per block slot of the MCU, one word: bits 0-1 component, bits 2-15 byte offset of
+ * its DC table (a multiple of four, so the field is the offset as it stands), bits
+ * 16-31 byte offset of its AC table.  Offsets are relative to the table array. */
 MJ_HD uint32_t mj_slot_pack(uint32_t comp, uint32_t tdc, uint32_t tac) {
-    return (comp & 3u) | ((tdc * (uint32_t) (sizeof(MjHuffDev) / 4)) << 2) | ((tac * (uint32_t) (sizeof(MjHuffDev) / 4)) << 16);
+    return (comp & 3u) | (tdc * (uint32_t) sizeof(MjHuffDev)) | ((tac * (uint32_t) sizeof(MjHuffDev)) << 16);
 }
 
 /* Wave-uniform description of the scan a lane is decoding. */
@@ -36,7 +39,7 @@ struct MjScanCtx {
     const uint32_t *stream;      /* the image's compacted stream, 32-bit words in file byte order; 16-byte aligned on the device */
     const unsigned char *tabs;   /* the image's MjHuffDev array (LDS on the device) */
     const MjHuffWalk *walk;      /* the matching canonical ranges (HBM on the device) */
-    const uint32_t *slots;       /* [bpm] mj_slot_pack() per block slot (LDS on the device) */
+    const uint32_t *slots;       /* [bpm + 1] mj_slot_pack() per block slot, entry bpm repeating entry 0 (LDS on the device) */
     int16_t *coefs;              /* block 0 of the image; 64 int16 per block, zigzag order */
     uint32_t bpm;                /* blocks per MCU */
     uint32_t wi_mask;            /* 0xFFFFFFFF; timing experiments narrow it so every lane reads the same few blocks */
@@ -52,6 +55,15 @@ MJ_HD uint32_t mj_align(uint32_t hi, uint32_t lo, uint32_t sh) {
     return __builtin_amdgcn_alignbit(hi, lo, sh);
 #else
     return (uint32_t) ((((uint64_t) hi << 32) | lo) >> sh);
+#endif
+}
+
+/* `width` bits of v starting at bit `off` (width 0 gives 0; off + width <= 32) */
+MJ_HD uint32_t mj_bfe(uint32_t v, uint32_t off, uint32_t width) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ubfe(v, off, width);
+#else
+    return width ? (v >> off) & (0xFFFFFFFFu >> (32u - width)) : 0u;
 #endif
 }
 
@@ -83,17 +95,18 @@ MJ_HD MjQuad mj_load_quad(const MjScanCtx &cx, uint32_t block) {
 /* Decoder state of one lane.  (p, k, c) is the state proper -- equal (p, k, c)
  * decode identically from there on; the rest is derived from it. */
 struct MjLane {
-    uint32_t hi, lo;    /* next `avail` stream bits, left-aligned in hi:lo, zero below */
-    int32_t avail;      /* > 32 after mj_refill */
+    uint32_t hi, lo;    /* the stream from bit p on, left-aligned in hi:lo, zero beyond the window */
+    uint32_t p;         /* bit offset of the next symbol */
+    uint32_t thr;       /* the window ends at bit thr + 32: more than 32 bits are left while p < thr */
     MjQuad cur;         /* words not yet in the window; cur.w0 is the next one */
     uint32_t ncur;      /* how many of them are left (1..4) */
     MjQuad nxt;         /* the following 16 bytes, requested one block ahead */
     uint32_t blk16;     /* index of the 16-byte block held in nxt */
-    uint32_t p;         /* bit offset of the next symbol */
     uint32_t k;         /* zigzag index of the next coefficient; 0: the DC symbol comes next */
     uint32_t c;         /* block slot inside the MCU */
     uint32_t slot;      /* cx.slots[c] */
-    uint32_t slot_nx;   /* cx.slots[next c]: fetched a block ahead so the lookup is off the critical path */
+    uint32_t slot_nx;   /* cx.slots[c + 1]: fetched a block ahead so the lookup is off the critical path */
+    uint32_t tcur;      /* byte offset of the table the next symbol is decoded with */
 };
 
 /* next stream word, byte-swapped to bit order */
@@ -124,21 +137,23 @@ MJ_HD void mj_lane_init(const MjScanCtx &cx, MjLane &L, uint32_t p, uint32_t k, 
     const uint32_t w0 = mj_take_word(cx, L), w1 = mj_take_word(cx, L);
     L.hi = sh ? mj_align(w0, w1, 32u - sh) : w0;
     L.lo = w1 << sh;
-    L.avail = 64 - (int32_t) sh;
     L.p = p;
+    L.thr = (p & ~31u) + 32u;
     L.k = k;
     L.c = c;
     L.slot = cx.slots[c];
-    L.slot_nx = cx.slots[(c + 1 == cx.bpm) ? 0 : c + 1];
+    L.slot_nx = cx.slots[c + 1];
+    L.tcur = k ? (L.slot >> 16) : (L.slot & 0xFFFCu);
 }
 
 /* Top the window up to more than 32 bits. */
 MJ_HD void mj_refill(const MjScanCtx &cx, MjLane &L) {
-    if (L.avail <= 32) {
+    if (L.p >= L.thr) {
         const uint32_t w = mj_take_word(cx, L);
-        L.hi |= (w >> 1) >> (L.avail - 1);         /* avail in [1, 32] */
-        L.lo = w << (32 - L.avail);
-        L.avail += 32;
+        const uint32_t sh = L.p - L.thr;           /* 0..31: 32 - sh bits are left */
+        L.hi |= (w >> 1) >> (31u - sh);
+        L.lo = w << sh;
+        L.thr += 32u;
     }
 }
 
@@ -152,6 +167,26 @@ struct MjSym {
     bool done;        /* the block ended with this symbol */
 };
 
+/* A first-level entry that is not a code: second-level table or canonical walk. */
+MJ_HD uint32_t mj_long_code(const MjScanCtx &cx, const MjLane &L, uint32_t e) {
+    const MjHuffDev *H = reinterpret_cast<const MjHuffDev *>(cx.tabs + L.tcur);
+    const uint32_t w = L.hi >> 16;
+    if (e & MJ_LUT_LONG) {
+        /* the MJ_SUB_BITS bits after the first MJ_LUT_BITS index the second level */
+        return H->sub[e & (MJ_SUB_MAX - 1)][w & (MJ_SUB_SIZE - 1)];
+    }
+    /* canonical ranges per length (the reference's own walk, decode.c:674-681) */
+    const MjHuffWalk *W = cx.walk + L.tcur / (uint32_t) sizeof(MjHuffDev);
+    const int is_ac = L.k != 0;
+    for (uint32_t l = MJ_LUT_BITS + 1; l <= 16; l++) {
+        const int32_t code = (int32_t) (w >> (16 - l));
+        if (code <= W->maxcode[l]) {
+            return mj_lut_entry(l, W->vals[(uint32_t) (W->valoff[l] + code) & 255u], is_ac);
+        }
+    }
+    return mj_lut_entry(16, 0, is_ac);   /* no such code: 16 bits are consumed as an end-of-block */
+}
+
 /*
  * Decode one symbol and advance the lane.  The caller has run mj_refill since the
  * previous step.  AC_VAL: also produce the value of AC coefficients (the writing
@@ -160,71 +195,39 @@ struct MjSym {
 template <bool AC_VAL>
 MJ_HD MjSym mj_step(const MjScanCtx &cx, MjLane &L) {
     MjSym s;
-    const bool isac = (L.k != 0);
-    const uint32_t toff = (isac ? (L.slot >> 16) : ((L.slot >> 2) & 0x3FFFu)) * 4u;
-    const unsigned char *T = cx.tabs + toff;
-    const uint32_t e = *reinterpret_cast<const uint16_t *>(T + ((L.hi >> (32 - MJ_LUT_BITS)) << 1));
-    uint32_t len = e >> 8, sym = e & 255u;
-    if (len - 1u >= 16u) {
-        /* not a short code: second-level table, canonical walk, or no code at all */
-        const MjHuffDev *H = reinterpret_cast<const MjHuffDev *>(T);
-        const MjHuffWalk *W = cx.walk + toff / (uint32_t) sizeof(MjHuffDev);
-        const uint32_t w = L.hi >> 16;
-        const uint32_t kind = e & 0xFF00u;
-        len = 16;
-        sym = 0;   /* no such code: 16 bits are consumed as an end-of-block */
-        if (kind == MJ_LUT_LONG) {
-            /* the MJ_SUB_BITS bits after the first MJ_LUT_BITS index the second level */
-            const uint32_t e2 = H->sub[e & (MJ_SUB_MAX - 1)][w & (MJ_SUB_SIZE - 1)];
-            if (e2) {
-                len = e2 >> 8;
-                sym = e2 & 255u;
-            }
-        } else if (kind == MJ_LUT_WALK) {
-            /* canonical ranges per length (the reference's own walk, decode.c:674-681) */
-            for (uint32_t l = MJ_LUT_BITS + 1; l <= 16; l++) {
-                const int32_t code = (int32_t) (w >> (16 - l));
-                if (code <= W->maxcode[l]) {
-                    sym = W->vals[(uint32_t) (W->valoff[l] + code) & 255u];
-                    len = l;
-                    break;
-                }
-            }
-        }
+    uint32_t e = *reinterpret_cast<const uint16_t *>(cx.tabs + L.tcur + ((L.hi >> (32 - MJ_LUT_BITS)) << 1));
+    if (MJ_E_LEN(e) == 0) {
+        e = mj_long_code(cx, L, e);
     }
-    const uint32_t size = sym & 15u;
-    const uint32_t used = len + size;          /* 1..31 */
-    s.dc = !isac;
+    const uint32_t size = mj_bfe(e, 7, 4);
+    const uint32_t used = MJ_E_LEN(e) + size;      /* 1..31 */
+    const uint32_t back = 32u - used;
+    s.dc = (L.k == 0);
     s.comp = L.slot & 3u;
     s.val = 0;
-    if (AC_VAL || !isac) {
+    if (AC_VAL || s.dc) {
         /* the `size` bits after the code, then EXTEND (decode.c:684-686, :716-718):
          * a leading 1 means the value as read, a leading 0 means value - 2^size + 1 */
-        const uint32_t rest = mj_align(L.hi, L.lo, 32u - len);
-        const uint32_t neg = (uint32_t) ((int32_t) ~rest >> 31);       /* all ones when the leading bit is 0 */
-        const uint32_t mag = ((rest ^ neg) >> 1) >> (31u - size);      /* size 0 -> 0 */
-        s.val = (int32_t) ((mag ^ neg) - neg);
+        const uint32_t v = mj_bfe(L.hi, back, size);
+        const uint32_t full = 1u << size;
+        s.val = (v < (full >> 1)) ? (int32_t) (v + 1u - full) : (int32_t) v;
     }
-    L.hi = mj_align(L.hi, L.lo, 32u - used);
+    L.hi = mj_align(L.hi, L.lo, back);
     L.lo <<= used;
-    L.avail -= (int32_t) used;
     L.p += used;
-    if (!isac) {
-        s.kpos = 0;
-        s.store = true;
-        L.k = 1;
-    } else {
-        const uint32_t kk = L.k + (sym >> 4);  /* run; ZRL (0xF0) has size 0 and nets +16 */
-        s.kpos = kk;
-        s.store = (size != 0) && (kk < 64);
-        L.k = (sym == 0) ? 64u : kk + 1;       /* 0x00 = end of block */
+    L.k += e & 127u;                               /* run + 1; 64 on end of block; ZRL nets 16 */
+    s.kpos = s.dc ? 0u : L.k - 1u;
+    s.store = s.dc || (size != 0 && L.k <= 64u);
+    if (s.dc) {
+        L.tcur = L.slot >> 16;
     }
-    s.done = (L.k >= 64);
+    s.done = (L.k >= 64u);
     if (s.done) {
         L.k = 0;
         L.c = (L.c + 1 == cx.bpm) ? 0 : L.c + 1;
         L.slot = L.slot_nx;
-        L.slot_nx = cx.slots[(L.c + 1 == cx.bpm) ? 0 : L.c + 1];
+        L.slot_nx = cx.slots[L.c + 1];
+        L.tcur = L.slot & 0xFFFCu;
     }
     return s;
 }

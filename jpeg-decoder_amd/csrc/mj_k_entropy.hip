@@ -96,8 +96,9 @@ __device__ __forceinline__ void load_tables(const MjDeviceBatch &b, const MjImag
     const uint4 *src = reinterpret_cast<const uint4 *>(set.tab);
     uint4 *dst = reinterpret_cast<uint4 *>(s_dyn);
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
-    if (threadIdx.x < im.bpm) {
-        lds_slots(b)[threadIdx.x] = mj_slot_pack(im.blk_comp[threadIdx.x], im.blk_dc[threadIdx.x], im.blk_ac[threadIdx.x]);
+    if (threadIdx.x <= im.bpm) {   /* entry bpm repeats entry 0: the slot after the last is the first */
+        const uint32_t i = (threadIdx.x == im.bpm) ? 0u : threadIdx.x;
+        lds_slots(b)[threadIdx.x] = mj_slot_pack(im.blk_comp[i], im.blk_dc[i], im.blk_ac[i]);
     }
 }
 

@@ -121,7 +121,7 @@ void mj_parsed_free(MjParsed *p) {
     memset(p, 0, sizeof *p);
 }
 
-void mj_flatten_huff(const HuffTable *ht, MjHuffDev *out, MjHuffWalk *walk) {
+void mj_flatten_huff(const HuffTable *ht, int is_ac, MjHuffDev *out, MjHuffWalk *walk) {
     memset(out, 0, sizeof *out);
     memset(walk, 0, sizeof *walk);
     walk->maxcode[0] = -1;
@@ -140,21 +140,22 @@ void mj_flatten_huff(const HuffTable *ht, MjHuffDev *out, MjHuffWalk *walk) {
         for (int i = 0; i < n && nvals < 256; i++, nvals++) {
             uint8_t sym = ht->symbols[l - 1][i];
             uint32_t code = (uint32_t) (mincode + i);
+            uint16_t entry = (uint16_t) mj_lut_entry((uint32_t) l, sym, is_ac);
             walk->vals[nvals] = sym;
             if (l <= MJ_LUT_BITS) {
                 /* every first-level index whose leading l bits are this code */
                 uint32_t first = code << (MJ_LUT_BITS - l);
                 uint32_t count = 1u << (MJ_LUT_BITS - l);
                 for (uint32_t j = 0; j < count && first + j < MJ_LUT_SIZE; j++) {
-                    out->lut[first + j] = (uint16_t) ((l << 8) | sym);
+                    out->lut[first + j] = entry;
                 }
             } else {
                 /* long code: its first MJ_LUT_BITS bits pick a second-level table */
                 uint32_t prefix = (code >> (l - MJ_LUT_BITS)) & (MJ_LUT_SIZE - 1);
                 uint16_t e = out->lut[prefix];
                 uint32_t si;
-                if ((e & 0xFF00u) == MJ_LUT_LONG) {
-                    si = e & 0xFFu;
+                if (e != 0 && MJ_E_LEN(e) == 0 && (e & MJ_LUT_LONG)) {
+                    si = e & (MJ_SUB_MAX - 1);
                 } else if (e == 0 && nsub < MJ_SUB_MAX) {
                     si = nsub++;
                     out->lut[prefix] = (uint16_t) (MJ_LUT_LONG | si);
@@ -167,9 +168,20 @@ void mj_flatten_huff(const HuffTable *ht, MjHuffDev *out, MjHuffWalk *walk) {
                 uint32_t first = (code & ((1u << rem) - 1u)) << (MJ_SUB_BITS - rem);
                 uint32_t count = 1u << (MJ_SUB_BITS - rem);
                 for (uint32_t j = 0; j < count && first + j < MJ_SUB_SIZE; j++) {
-                    out->sub[si][first + j] = (uint16_t) ((l << 8) | sym);
+                    out->sub[si][first + j] = entry;
                 }
             }
+        }
+    }
+    /* prefixes no code has: sixteen bits are taken as an end of block (AC) or a zero
+     * difference (DC), resolved here so the kernels never see an empty entry */
+    const uint16_t none = (uint16_t) mj_lut_entry(16, 0, is_ac);
+    for (uint32_t j = 0; j < MJ_LUT_SIZE; j++) {
+        if (out->lut[j] == 0) out->lut[j] = none;
+    }
+    for (uint32_t t = 0; t < MJ_SUB_MAX; t++) {
+        for (uint32_t j = 0; j < MJ_SUB_SIZE; j++) {
+            if (out->sub[t][j] == 0) out->sub[t][j] = none;
         }
     }
 }
@@ -286,12 +298,12 @@ int mj_flatten_image(const MjParsed *p, size_t file_len, MjImageDev *img, MjHuff
         }
         if (dc_slot[td] < 0) {
             dc_slot[td] = (int) set->ntab;
-            mj_flatten_huff(&p->hts.DCAC[TC_DC][td], &set->tab[set->ntab], &set->walk[set->ntab]);
+            mj_flatten_huff(&p->hts.DCAC[TC_DC][td], 0, &set->tab[set->ntab], &set->walk[set->ntab]);
             set->ntab++;
         }
         if (ac_slot[ta] < 0) {
             ac_slot[ta] = (int) set->ntab;
-            mj_flatten_huff(&p->hts.DCAC[TC_AC][ta], &set->tab[set->ntab], &set->walk[set->ntab]);
+            mj_flatten_huff(&p->hts.DCAC[TC_AC][ta], 1, &set->tab[set->ntab], &set->walk[set->ntab]);
             set->ntab++;
         }
         const Component *c = &fh->cs[ci];
