@@ -116,14 +116,10 @@ int64_t mj_emu_decode_coefs(const uint8_t *file, size_t len, int16_t *coefs, int
 
     MjScanCtx cx;
     cx.stream = (const uint32_t *) L.cmp.data();
-    uint32_t slots[MJ_MAX_BPM + 2];
-    for (uint32_t i = 0; i < img.bpm; i++) slots[i] = mj_slot_pack(img.blk_comp[i], img.blk_dc[i], img.blk_ac[i]);
-    slots[img.bpm] = slots[0];
+    mj_ctx_slots(cx, img.bpm, img.blk_comp, img.blk_dc, img.blk_ac);
     cx.tabs = (const unsigned char *) set->tab;
     cx.walk = set->walk;
-    cx.slots = slots;
     cx.coefs = coefs;
-    cx.bpm = img.bpm;
     cx.wi_mask = 0xFFFFFFFFu;
 
     int64_t st_subs = 0, st_rounds = 0, st_maxr = 0, st_seqs = 0, st_multi = 0, st_fix = 0, st_tasks = 0;

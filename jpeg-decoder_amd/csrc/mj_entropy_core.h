@@ -27,11 +27,12 @@
 #define MJ_HD static inline
 #endif
 
-/* Per block slot of the MCU, one word: bits 0-1 component, bits 2-15 byte offset of
- * its DC table (a multiple of four, so the field is the offset as it stands), bits
- * 16-31 byte offset of its AC table.  Offsets are relative to the table array. */
-MJ_HD uint32_t mj_slot_pack(uint32_t comp, uint32_t tdc, uint32_t tac) {
-    return (comp & 3u) | (tdc * (uint32_t) sizeof(MjHuffDev)) | ((tac * (uint32_t) sizeof(MjHuffDev)) << 16);
+/* Per block slot of the MCU, eight bits: bits 0-1 component, bits 2-4 index of its DC
+ * table, bits 5-7 index of its AC table (indices into the MjHuffDev array).  The
+ * descriptors of all slots of an MCU (at most ten) travel as three wave-uniform words,
+ * so switching block costs a few ALU operations and no memory access. */
+MJ_HD uint32_t mj_slot_desc(uint32_t comp, uint32_t tdc, uint32_t tac) {
+    return (comp & 3u) | ((tdc & 7u) << 2) | ((tac & 7u) << 5);
 }
 
 /* Wave-uniform description of the scan a lane is decoding. */
@@ -39,11 +40,34 @@ struct MjScanCtx {
     const uint32_t *stream;      /* the image's compacted stream, 32-bit words in file byte order; 16-byte aligned on the device */
     const unsigned char *tabs;   /* the image's MjHuffDev array (LDS on the device) */
     const MjHuffWalk *walk;      /* the matching canonical ranges (HBM on the device) */
-    const uint32_t *slots;       /* [bpm + 1] mj_slot_pack() per block slot, entry bpm repeating entry 0 (LDS on the device) */
+    uint32_t slotw[3];           /* mj_slot_desc() of slot i in byte i & 3 of word i >> 2 */
     int16_t *coefs;              /* block 0 of the image; 64 int16 per block, zigzag order */
     uint32_t bpm;                /* blocks per MCU */
     uint32_t wi_mask;            /* 0xFFFFFFFF; timing experiments narrow it so every lane reads the same few blocks */
 };
+
+/* fill cx.slotw from per-slot component / table indices */
+MJ_HD void mj_ctx_slots(MjScanCtx &cx, uint32_t bpm, const uint8_t *comp, const uint8_t *tdc, const uint8_t *tac) {
+    cx.slotw[0] = cx.slotw[1] = cx.slotw[2] = 0;
+    for (uint32_t i = 0; i < MJ_MAX_BPM; i++) {
+        const uint32_t d = (i < bpm) ? mj_slot_desc(comp[i], tdc[i], tac[i]) : 0u;
+        if ((i >> 2) == 0) cx.slotw[0] |= d << (8 * (i & 3));
+        if ((i >> 2) == 1) cx.slotw[1] |= d << (8 * (i & 3));
+        if ((i >> 2) == 2) cx.slotw[2] |= d << (8 * (i & 3));
+    }
+    cx.bpm = bpm;
+}
+
+MJ_HD uint32_t mj_slot_of(const MjScanCtx &cx, uint32_t c) {
+    const uint32_t w = (c < 4) ? cx.slotw[0] : (c < 8) ? cx.slotw[1] : cx.slotw[2];
+    return (w >> ((c & 3u) * 8u)) & 0xFFu;
+}
+MJ_HD uint32_t mj_slot_tdc(uint32_t slot) {   /* byte offset of the slot's DC table */
+    return ((slot >> 2) & 7u) * (uint32_t) sizeof(MjHuffDev);
+}
+MJ_HD uint32_t mj_slot_tac(uint32_t slot) {
+    return (slot >> 5) * (uint32_t) sizeof(MjHuffDev);
+}
 
 MJ_HD uint32_t mj_be32(uint32_t v) {
     return __builtin_bswap32(v);
@@ -98,26 +122,25 @@ struct MjLane {
     uint32_t hi, lo;    /* the stream from bit p on, left-aligned in hi:lo, zero beyond the window */
     uint32_t p;         /* bit offset of the next symbol */
     uint32_t thr;       /* the window ends at bit thr + 32: more than 32 bits are left while p < thr */
-    MjQuad cur;         /* words not yet in the window; cur.w0 is the next one */
-    uint32_t ncur;      /* how many of them are left (1..4) */
+    MjQuad cur;         /* the 16-byte block the next word comes from */
+    uint32_t icur;      /* index (0..3) of that word */
     MjQuad nxt;         /* the following 16 bytes, requested one block ahead */
     uint32_t blk16;     /* index of the 16-byte block held in nxt */
     uint32_t k;         /* zigzag index of the next coefficient; 0: the DC symbol comes next */
     uint32_t c;         /* block slot inside the MCU */
-    uint32_t slot;      /* cx.slots[c] */
-    uint32_t slot_nx;   /* cx.slots[c + 1]: fetched a block ahead so the lookup is off the critical path */
+    uint32_t slot;      /* mj_slot_of(c) */
     uint32_t tcur;      /* byte offset of the table the next symbol is decoded with */
 };
 
 /* next stream word, byte-swapped to bit order */
 MJ_HD uint32_t mj_take_word(const MjScanCtx &cx, MjLane &L) {
-    const uint32_t w = mj_be32(L.cur.w0);
-    L.cur.w0 = L.cur.w1;
-    L.cur.w1 = L.cur.w2;
-    L.cur.w2 = L.cur.w3;
-    if (--L.ncur == 0) {
+    const uint32_t i = L.icur;
+    const uint32_t lo2 = (i & 1u) ? L.cur.w1 : L.cur.w0, hi2 = (i & 1u) ? L.cur.w3 : L.cur.w2;
+    const uint32_t w = mj_be32((i & 2u) ? hi2 : lo2);
+    L.icur = i + 1;
+    if (L.icur == 4) {
         L.cur = L.nxt;
-        L.ncur = 4;
+        L.icur = 0;
         L.blk16++;
         L.nxt = mj_load_quad(cx, L.blk16);   /* not touched for another four words */
     }
@@ -130,10 +153,7 @@ MJ_HD void mj_lane_init(const MjScanCtx &cx, MjLane &L, uint32_t p, uint32_t k, 
     L.cur = mj_load_quad(cx, L.blk16);
     L.blk16++;
     L.nxt = mj_load_quad(cx, L.blk16);
-    L.ncur = 4;
-    for (uint32_t i = wi & 3u; i != 0; i--) {
-        (void) mj_take_word(cx, L);
-    }
+    L.icur = wi & 3u;
     const uint32_t w0 = mj_take_word(cx, L), w1 = mj_take_word(cx, L);
     L.hi = sh ? mj_align(w0, w1, 32u - sh) : w0;
     L.lo = w1 << sh;
@@ -141,9 +161,8 @@ MJ_HD void mj_lane_init(const MjScanCtx &cx, MjLane &L, uint32_t p, uint32_t k, 
     L.thr = (p & ~31u) + 32u;
     L.k = k;
     L.c = c;
-    L.slot = cx.slots[c];
-    L.slot_nx = cx.slots[c + 1];
-    L.tcur = k ? (L.slot >> 16) : (L.slot & 0xFFFCu);
+    L.slot = mj_slot_of(cx, c);
+    L.tcur = k ? mj_slot_tac(L.slot) : mj_slot_tdc(L.slot);
 }
 
 /* Top the window up to more than 32 bits. */
@@ -157,13 +176,29 @@ MJ_HD void mj_refill(const MjScanCtx &cx, MjLane &L) {
     }
 }
 
+/* Per-component DC accumulators (decode.c:682-690; the int16 wrap is applied when a
+ * value is stored): lane-private words acc[comp * stride], in LDS on the device so
+ * that the component index costs one address computation instead of a select per
+ * component.  RETURN: give back the updated accumulator. */
+template <bool RETURN>
+MJ_HD int32_t mj_dc_add(int32_t *acc, uint32_t stride, uint32_t comp, int32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (RETURN) {
+        return __hip_atomic_fetch_add(acc + comp * stride, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) + v;
+    }
+    (void) __hip_atomic_fetch_add(acc + comp * stride, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    return 0;
+#else
+    acc[comp * stride] += v;
+    return acc[comp * stride];
+#endif
+}
+
 /* What one symbol did. */
 struct MjSym {
-    int32_t val;      /* DC difference, or AC coefficient value (0 when VAL is off for AC) */
+    int32_t val;      /* WRITE only: the coefficient value (for DC: the predictor after the addition) */
     uint32_t kpos;    /* zigzag position the value belongs to (0 for DC) */
-    uint32_t comp;    /* component of the block the symbol belongs to */
-    bool dc;          /* the symbol was the block's DC */
-    bool store;       /* val is a coefficient to store (DC always; AC when size != 0 and in range) */
+    bool store;       /* WRITE only: val is a coefficient to store (DC always; AC when size != 0 and in range) */
     bool done;        /* the block ended with this symbol */
 };
 
@@ -188,12 +223,14 @@ MJ_HD uint32_t mj_long_code(const MjScanCtx &cx, const MjLane &L, uint32_t e) {
 }
 
 /*
- * Decode one symbol and advance the lane.  The caller has run mj_refill since the
- * previous step.  AC_VAL: also produce the value of AC coefficients (the writing
- * pass needs it, the synchronisation passes only need the bit count).
+ * Decode one symbol and advance the lane: what decode_data_unit (decode.c:665-723)
+ * does per symbol.  The caller has run mj_refill since the previous step.  A DC
+ * difference is added to its component's accumulator acc[comp * stride]; nb counts
+ * the blocks that end.  WRITE: also produce the coefficient to store (the writing
+ * pass needs it, the synchronisation passes only need bit counts and DC sums).
  */
-template <bool AC_VAL>
-MJ_HD MjSym mj_step(const MjScanCtx &cx, MjLane &L) {
+template <bool WRITE>
+MJ_HD MjSym mj_step(const MjScanCtx &cx, MjLane &L, int32_t *acc, uint32_t stride, uint32_t &nb) {
     MjSym s;
     uint32_t e = *reinterpret_cast<const uint16_t *>(cx.tabs + L.tcur + ((L.hi >> (32 - MJ_LUT_BITS)) << 1));
     if (MJ_E_LEN(e) == 0) {
@@ -202,47 +239,34 @@ MJ_HD MjSym mj_step(const MjScanCtx &cx, MjLane &L) {
     const uint32_t size = mj_bfe(e, 7, 4);
     const uint32_t used = MJ_E_LEN(e) + size;      /* 1..31 */
     const uint32_t back = 32u - used;
-    s.dc = (L.k == 0);
-    s.comp = L.slot & 3u;
+    const bool dc = (L.k == 0);
     s.val = 0;
-    if (AC_VAL || s.dc) {
+    if (WRITE || dc) {
         /* the `size` bits after the code, then EXTEND (decode.c:684-686, :716-718):
          * a leading 1 means the value as read, a leading 0 means value - 2^size + 1 */
         const uint32_t v = mj_bfe(L.hi, back, size);
         const uint32_t full = 1u << size;
         s.val = (v < (full >> 1)) ? (int32_t) (v + 1u - full) : (int32_t) v;
+        if (dc) {
+            s.val = mj_dc_add<WRITE>(acc, stride, L.slot & 3u, s.val);
+            L.tcur = mj_slot_tac(L.slot);
+        }
     }
     L.hi = mj_align(L.hi, L.lo, back);
     L.lo <<= used;
     L.p += used;
     L.k += e & 127u;                               /* run + 1; 64 on end of block; ZRL nets 16 */
-    s.kpos = s.dc ? 0u : L.k - 1u;
-    s.store = s.dc || (size != 0 && L.k <= 64u);
-    if (s.dc) {
-        L.tcur = L.slot >> 16;
-    }
+    s.kpos = dc ? 0u : L.k - 1u;
+    s.store = dc || (size != 0 && L.k <= 64u);
     s.done = (L.k >= 64u);
     if (s.done) {
         L.k = 0;
         L.c = (L.c + 1 == cx.bpm) ? 0 : L.c + 1;
-        L.slot = L.slot_nx;
-        L.slot_nx = cx.slots[L.c + 1];
-        L.tcur = L.slot & 0xFFFCu;
+        L.slot = mj_slot_of(cx, L.c);
+        L.tcur = mj_slot_tdc(L.slot);
+        nb++;
     }
     return s;
-}
-
-/* Per-component DC accumulators (decode.c:682-690; the int16 wrap is applied when a
- * value is stored): lane-private words acc[comp * stride], in LDS on the device so
- * that the component index costs one address computation instead of a select per
- * component.  Returns the updated accumulator. */
-MJ_HD int32_t mj_dc_add(int32_t *acc, uint32_t stride, uint32_t comp, int32_t v) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __hip_atomic_fetch_add(acc + comp * stride, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) + v;
-#else
-    acc[comp * stride] += v;
-    return acc[comp * stride];
-#endif
 }
 
 /*
@@ -253,11 +277,7 @@ MJ_HD int32_t mj_dc_add(int32_t *acc, uint32_t stride, uint32_t comp, int32_t v)
 MJ_HD void mj_run_span(const MjScanCtx &cx, MjLane &L, uint32_t end, uint32_t &nb, int32_t *acc, uint32_t stride) {
     while (L.p < end) {
         mj_refill(cx, L);
-        const MjSym s = mj_step<false>(cx, L);
-        if (s.dc) {
-            (void) mj_dc_add(acc, stride, s.comp, s.val);
-        }
-        nb += s.done ? 1u : 0u;
+        (void) mj_step<false>(cx, L, acc, stride, nb);
     }
 }
 
@@ -289,14 +309,11 @@ MJ_HD void mj_decode_span(const MjScanCtx &cx, uint32_t &p, uint32_t &k, uint32_
 MJ_HD void mj_write_step(const MjScanCtx &cx, MjLane &L, bool &skip, uint32_t &blk, uint32_t blk_end, int32_t *acc,
                          uint32_t stride, int16_t *blkbuf, bool &fin, uint32_t &fin_blk) {
     mj_refill(cx, L);
-    const MjSym s = mj_step<true>(cx, L);
+    uint32_t ended = 0;
+    const MjSym s = mj_step<true>(cx, L, acc, stride, ended);
     const bool mine = !skip && blk < blk_end;
-    int32_t v = s.val;
-    if (s.dc) {
-        v = mj_dc_add(acc, stride, s.comp, s.val);
-    }
     if (s.store && mine) {
-        blkbuf[s.kpos] = (int16_t) v;
+        blkbuf[s.kpos] = (int16_t) s.val;
     }
     fin = false;
     if (s.done) {

@@ -77,9 +77,6 @@ extern __shared__ __align__(16) unsigned char s_dyn[];
 
 /* LDS carve-up shared by all entropy kernels:
  * [Huffman tables][16 slot words][DC accumulators: waves x 4 components x 64 lanes]... */
-__device__ __forceinline__ uint32_t *lds_slots(const MjDeviceBatch &b) {
-    return reinterpret_cast<uint32_t *>(s_dyn + b.max_ntab * sizeof(MjHuffDev));
-}
 __device__ __forceinline__ int32_t *lds_dc(const MjDeviceBatch &b) {
     return reinterpret_cast<int32_t *>(s_dyn + b.max_ntab * sizeof(MjHuffDev) + 16 * sizeof(uint32_t));
 }
@@ -96,10 +93,6 @@ __device__ __forceinline__ void load_tables(const MjDeviceBatch &b, const MjImag
     const uint4 *src = reinterpret_cast<const uint4 *>(set.tab);
     uint4 *dst = reinterpret_cast<uint4 *>(s_dyn);
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
-    if (threadIdx.x <= im.bpm) {   /* entry bpm repeats entry 0: the slot after the last is the first */
-        const uint32_t i = (threadIdx.x == im.bpm) ? 0u : threadIdx.x;
-        lds_slots(b)[threadIdx.x] = mj_slot_pack(im.blk_comp[i], im.blk_dc[i], im.blk_ac[i]);
-    }
 }
 
 __device__ __forceinline__ MjScanCtx make_ctx(const MjDeviceBatch &b, const MjImageDev &im) {
@@ -107,9 +100,8 @@ __device__ __forceinline__ MjScanCtx make_ctx(const MjDeviceBatch &b, const MjIm
     cx.stream = reinterpret_cast<const uint32_t *>(b.cmp + im.cmp_off);
     cx.tabs = s_dyn;
     cx.walk = b.sets[im.huff_set].walk;
-    cx.slots = lds_slots(b);
+    mj_ctx_slots(cx, im.bpm, im.blk_comp, im.blk_dc, im.blk_ac);
     cx.coefs = b.coefs + im.coef_off * 64;
-    cx.bpm = im.bpm;
     cx.wi_mask = (b.dbg & 32u) ? 15u : 0xFFFFFFFFu;
     return cx;
 }
@@ -596,11 +588,9 @@ __global__ __launch_bounds__(TPB) void mj_k_entropy_serial(MjDeviceBatch b) {
         acc[0] = acc[64] = acc[128] = acc[192] = 0;
         while (L.p < end && blk < blk_end) {
             mj_refill(cx, L);
-            const MjSym s = mj_step<true>(cx, L);
-            int32_t v = s.val;
-            if (s.dc) v = mj_dc_add(acc, 64, s.comp, s.val);
-            if (s.store) cx.coefs[(uint64_t) blk * 64 + s.kpos] = (int16_t) v;
-            blk += s.done ? 1u : 0u;
+            const uint32_t at = blk;
+            const MjSym s = mj_step<true>(cx, L, acc, 64, blk);
+            if (s.store) cx.coefs[(uint64_t) at * 64 + s.kpos] = (int16_t) s.val;
         }
     }
 }
