@@ -40,7 +40,7 @@ struct MjScanCtx {
     const uint32_t *stream;      /* the image's compacted stream, 32-bit words in file byte order; 16-byte aligned on the device */
     const unsigned char *tabs;   /* the image's MjHuffDev array (LDS on the device) */
     const MjHuffWalk *walk;      /* the matching canonical ranges (HBM on the device) */
-    uint32_t slotw[3];           /* mj_slot_desc() of slot i in byte i & 3 of word i >> 2 */
+    uint32_t slotw0, slotw1, slotw2; /* mj_slot_desc() of slot i in byte i & 3 of word i >> 2 (separate members: never indexed) */
     int16_t *coefs;              /* block 0 of the image; 64 int16 per block, zigzag order */
     uint32_t bpm;                /* blocks per MCU */
     uint32_t wi_mask;            /* 0xFFFFFFFF; timing experiments narrow it so every lane reads the same few blocks */
@@ -48,25 +48,42 @@ struct MjScanCtx {
 
 /* fill cx.slotw from per-slot component / table indices */
 MJ_HD void mj_ctx_slots(MjScanCtx &cx, uint32_t bpm, const uint8_t *comp, const uint8_t *tdc, const uint8_t *tac) {
-    cx.slotw[0] = cx.slotw[1] = cx.slotw[2] = 0;
+    uint32_t w0 = 0, w1 = 0, w2 = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
     for (uint32_t i = 0; i < MJ_MAX_BPM; i++) {
-        const uint32_t d = (i < bpm) ? mj_slot_desc(comp[i], tdc[i], tac[i]) : 0u;
-        if ((i >> 2) == 0) cx.slotw[0] |= d << (8 * (i & 3));
-        if ((i >> 2) == 1) cx.slotw[1] |= d << (8 * (i & 3));
-        if ((i >> 2) == 2) cx.slotw[2] |= d << (8 * (i & 3));
+        const uint32_t d = (i < bpm) ? mj_slot_desc(comp[i], tdc[i], tac[i]) << (8 * (i & 3)) : 0u;
+        if (i < 4) w0 |= d;
+        else if (i < 8) w1 |= d;
+        else w2 |= d;
     }
+    cx.slotw0 = w0;
+    cx.slotw1 = w1;
+    cx.slotw2 = w2;
     cx.bpm = bpm;
 }
 
 MJ_HD uint32_t mj_slot_of(const MjScanCtx &cx, uint32_t c) {
-    const uint32_t w = (c < 4) ? cx.slotw[0] : (c < 8) ? cx.slotw[1] : cx.slotw[2];
-    return (w >> ((c & 3u) * 8u)) & 0xFFu;
+    /* shifts, not a choice between the words themselves: a select between struct
+     * members becomes a select between their addresses and sends the struct to memory */
+    const uint64_t w01 = ((uint64_t) cx.slotw1 << 32) | cx.slotw0;
+    const uint32_t a = (uint32_t) (w01 >> ((c & 7u) * 8u));
+    const uint32_t b = cx.slotw2 >> ((c & 1u) * 8u);
+    return ((c < 8) ? a : b) & 0xFFu;
+}
+MJ_HD uint32_t mj_mul24(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul24(a, b);
+#else
+    return a * b;
+#endif
 }
 MJ_HD uint32_t mj_slot_tdc(uint32_t slot) {   /* byte offset of the slot's DC table */
-    return ((slot >> 2) & 7u) * (uint32_t) sizeof(MjHuffDev);
+    return mj_mul24((slot >> 2) & 7u, (uint32_t) sizeof(MjHuffDev));
 }
 MJ_HD uint32_t mj_slot_tac(uint32_t slot) {
-    return (slot >> 5) * (uint32_t) sizeof(MjHuffDev);
+    return mj_mul24(slot >> 5, (uint32_t) sizeof(MjHuffDev));
 }
 
 MJ_HD uint32_t mj_be32(uint32_t v) {
