@@ -61,11 +61,25 @@ typedef struct {
     uint32_t pad_[2];
 } MjHuffWalk;                  /* canonical ranges, read from HBM only on MJ_LUT_WALK entries */
 
+/* Runs of AC symbols that one first-level lookup resolves at once, for the passes that
+ * only count (no coefficient values): entry i describes the longest run of two or more
+ * whole symbols whose codes lie inside the MJ_LUT_BITS bits i (value bits may stick
+ * out), ending at the latest with an end of block:
+ *   bits 15-11  bits the run consumes
+ *   bits 10-7   zigzag steps of all its symbols but the last (at most 15)
+ *   bits 6-0    zigzag step of the last symbol (64 for end of block)
+ * 0 = no such run.  The run may be taken only if the block does not end before its
+ * last symbol, i.e. k + (bits 10-7) < 64. */
+typedef struct {
+    uint16_t pair[MJ_LUT_SIZE];
+} MjHuffPair;
+
 typedef struct {
     uint32_t ntab;
     uint32_t pad_[3];
     MjHuffDev tab[MJ_MAX_TABS];
     MjHuffWalk walk[MJ_MAX_TABS];
+    MjHuffPair pair[MJ_MAX_TABS];   /* all zero for DC tables */
 } MjHuffSet;
 
 typedef struct {

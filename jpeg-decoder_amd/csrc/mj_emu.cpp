@@ -119,6 +119,7 @@ int64_t mj_emu_decode_coefs(const uint8_t *file, size_t len, int16_t *coefs, int
     mj_ctx_slots(cx, img.bpm, img.blk_comp, img.blk_dc, img.blk_ac);
     cx.tabs = (const unsigned char *) set->tab;
     cx.walk = set->walk;
+    cx.pairs = (const unsigned char *) set->pair;
     cx.coefs = coefs;
     cx.wi_mask = 0xFFFFFFFFu;
 

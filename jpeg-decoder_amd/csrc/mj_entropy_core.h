@@ -40,6 +40,7 @@ struct MjScanCtx {
     const uint32_t *stream;      /* the image's compacted stream, 32-bit words in file byte order; 16-byte aligned on the device */
     const unsigned char *tabs;   /* the image's MjHuffDev array (LDS on the device) */
     const MjHuffWalk *walk;      /* the matching canonical ranges (HBM on the device) */
+    const unsigned char *pairs;  /* the matching MjHuffPair array (LDS on the device); only the counting passes read it */
     uint32_t slotw0, slotw1, slotw2; /* mj_slot_desc() of slot i in byte i & 3 of word i >> 2 (separate members: never indexed) */
     int16_t *coefs;              /* block 0 of the image; 64 int16 per block, zigzag order */
     uint32_t bpm;                /* blocks per MCU */
@@ -147,6 +148,7 @@ struct MjLane {
     uint32_t c;         /* block slot inside the MCU */
     uint32_t slot;      /* mj_slot_of(c) */
     uint32_t tcur;      /* byte offset of the table the next symbol is decoded with */
+    uint32_t pcur;      /* byte offset of the MjHuffPair of the slot's AC table */
 };
 
 /* next stream word, byte-swapped to bit order */
@@ -180,6 +182,7 @@ MJ_HD void mj_lane_init(const MjScanCtx &cx, MjLane &L, uint32_t p, uint32_t k, 
     L.c = c;
     L.slot = mj_slot_of(cx, c);
     L.tcur = k ? mj_slot_tac(L.slot) : mj_slot_tdc(L.slot);
+    L.pcur = (L.slot >> 5) * (uint32_t) sizeof(MjHuffPair);
 }
 
 /* Top the window up to more than 32 bits. */
@@ -247,16 +250,31 @@ MJ_HD uint32_t mj_long_code(const MjScanCtx &cx, const MjLane &L, uint32_t e) {
  * pass needs it, the synchronisation passes only need bit counts and DC sums).
  */
 template <bool WRITE>
-MJ_HD MjSym mj_step(const MjScanCtx &cx, MjLane &L, int32_t *acc, uint32_t stride, uint32_t &nb) {
+MJ_HD MjSym mj_step(const MjScanCtx &cx, MjLane &L, int32_t *acc, uint32_t stride, uint32_t &nb, uint32_t end) {
     MjSym s;
-    uint32_t e = *reinterpret_cast<const uint16_t *>(cx.tabs + L.tcur + ((L.hi >> (32 - MJ_LUT_BITS)) << 1));
+    const uint32_t idx2 = (L.hi >> (32 - MJ_LUT_BITS)) << 1;
+    uint32_t e = *reinterpret_cast<const uint16_t *>(cx.tabs + L.tcur + idx2);
+    uint32_t d = 0;
+    if (!WRITE) {
+        d = *reinterpret_cast<const uint16_t *>(cx.pairs + L.pcur + idx2);
+    }
     if (MJ_E_LEN(e) == 0) {
         e = mj_long_code(cx, L, e);
     }
     const uint32_t size = mj_bfe(e, 7, 4);
-    const uint32_t used = MJ_E_LEN(e) + size;      /* 1..31 */
-    const uint32_t back = 32u - used;
+    uint32_t used = MJ_E_LEN(e) + size;            /* 1..31 */
+    uint32_t step = e & 127u;                      /* run + 1; 64 on end of block; ZRL nets 16 */
     const bool dc = (L.k == 0);
+    if (!WRITE) {
+        /* a run of whole AC symbols in one go, when the block lasts up to the run's last
+         * symbol and the run ends inside the span: exactly what that many single steps
+         * would do, including where the span stops */
+        const uint32_t run_used = d >> 11, run_before = mj_bfe(d, 7, 4);
+        const bool run = (d != 0) && !dc && (L.k + run_before < 64u) && (L.p + run_used <= end);
+        used = run ? run_used : used;
+        step = run ? run_before + (d & 127u) : step;
+    }
+    const uint32_t back = 32u - used;
     s.val = 0;
     if (WRITE || dc) {
         /* the `size` bits after the code, then EXTEND (decode.c:684-686, :716-718):
@@ -272,7 +290,7 @@ MJ_HD MjSym mj_step(const MjScanCtx &cx, MjLane &L, int32_t *acc, uint32_t strid
     L.hi = mj_align(L.hi, L.lo, back);
     L.lo <<= used;
     L.p += used;
-    L.k += e & 127u;                               /* run + 1; 64 on end of block; ZRL nets 16 */
+    L.k += step;
     s.kpos = dc ? 0u : L.k - 1u;
     s.store = dc || (size != 0 && L.k <= 64u);
     s.done = (L.k >= 64u);
@@ -281,6 +299,7 @@ MJ_HD MjSym mj_step(const MjScanCtx &cx, MjLane &L, int32_t *acc, uint32_t strid
         L.c = (L.c + 1 == cx.bpm) ? 0 : L.c + 1;
         L.slot = mj_slot_of(cx, L.c);
         L.tcur = mj_slot_tdc(L.slot);
+        L.pcur = (L.slot >> 5) * (uint32_t) sizeof(MjHuffPair);
         nb++;
     }
     return s;
@@ -294,7 +313,7 @@ MJ_HD MjSym mj_step(const MjScanCtx &cx, MjLane &L, int32_t *acc, uint32_t strid
 MJ_HD void mj_run_span(const MjScanCtx &cx, MjLane &L, uint32_t end, uint32_t &nb, int32_t *acc, uint32_t stride) {
     while (L.p < end) {
         mj_refill(cx, L);
-        (void) mj_step<false>(cx, L, acc, stride, nb);
+        (void) mj_step<false>(cx, L, acc, stride, nb, end);
     }
 }
 
@@ -327,7 +346,7 @@ MJ_HD void mj_write_step(const MjScanCtx &cx, MjLane &L, bool &skip, uint32_t &b
                          uint32_t stride, int16_t *blkbuf, bool &fin, uint32_t &fin_blk) {
     mj_refill(cx, L);
     uint32_t ended = 0;
-    const MjSym s = mj_step<true>(cx, L, acc, stride, ended);
+    const MjSym s = mj_step<true>(cx, L, acc, stride, ended, 0);
     const bool mine = !skip && blk < blk_end;
     if (s.store && mine) {
         blkbuf[s.kpos] = (int16_t) s.val;

@@ -85,21 +85,28 @@ __device__ __forceinline__ unsigned char *lds_after_dc(const MjDeviceBatch &b, u
     return reinterpret_cast<unsigned char *>(lds_dc(b)) + waves * DC_WAVE_BYTES;
 }
 
-/* cooperative copy of the image's Huffman tables and per-slot table selection into
- * LDS (the caller synchronises) */
-__device__ __forceinline__ void load_tables(const MjDeviceBatch &b, const MjImageDev &im) {
+/* cooperative copy of the image's Huffman tables into LDS -- and, for the counting
+ * kernels, of the symbol-run tables into `pairs` (the caller synchronises) */
+__device__ __forceinline__ void load_tables(const MjDeviceBatch &b, const MjImageDev &im, unsigned char *pairs) {
     const MjHuffSet &set = b.sets[im.huff_set];
     const uint32_t n = set.ntab * (uint32_t) (sizeof(MjHuffDev) / 16);
     const uint4 *src = reinterpret_cast<const uint4 *>(set.tab);
     uint4 *dst = reinterpret_cast<uint4 *>(s_dyn);
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+    if (pairs) {
+        const uint32_t np = set.ntab * (uint32_t) (sizeof(MjHuffPair) / 16);
+        const uint4 *psrc = reinterpret_cast<const uint4 *>(set.pair);
+        uint4 *pdst = reinterpret_cast<uint4 *>(pairs);
+        for (uint32_t i = threadIdx.x; i < np; i += blockDim.x) pdst[i] = psrc[i];
+    }
 }
 
-__device__ __forceinline__ MjScanCtx make_ctx(const MjDeviceBatch &b, const MjImageDev &im) {
+__device__ __forceinline__ MjScanCtx make_ctx(const MjDeviceBatch &b, const MjImageDev &im, const unsigned char *pairs) {
     MjScanCtx cx;
     cx.stream = reinterpret_cast<const uint32_t *>(b.cmp + im.cmp_off);
     cx.tabs = s_dyn;
     cx.walk = b.sets[im.huff_set].walk;
+    cx.pairs = pairs;
     mj_ctx_slots(cx, im.bpm, im.blk_comp, im.blk_dc, im.blk_ac);
     cx.coefs = b.coefs + im.coef_off * 64;
     cx.wi_mask = (b.dbg & 32u) ? 15u : 0xFFFFFFFFu;
@@ -211,13 +218,14 @@ __global__ __launch_bounds__(SYNC_TPB) void mj_k_entropy_sync(MjDeviceBatch b) {
     const uint32_t seq0 = (blockIdx.x - im.wg_first) * SYNC_WAVES;
     if (seq0 >= n_seq) return;
 
-    /* dynamic LDS: [tables][slots][DC accumulators][sequence geometry][3 queue counters][2 queues] */
+    /* dynamic LDS: [tables][DC accumulators][sequence geometry][3 queue counters][2 queues][symbol-run tables] */
     SeqGeo *s_geo = reinterpret_cast<SeqGeo *>(lds_after_dc(b, SYNC_WAVES));
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_geo + SYNC_WAVES);
     uint2 *s_queue = reinterpret_cast<uint2 *>(s_cnt + 4);
+    unsigned char *s_pairs = reinterpret_cast<unsigned char *>(s_queue + 2 * SYNC_TPB);
 
     const uint32_t S = im.sub_bits, G = im.lane_subs, SQ = MJ_SEQ_LANES * G;
-    load_tables(b, im);
+    load_tables(b, im, s_pairs);
     if (threadIdx.x < SYNC_WAVES) {
         SeqGeo sg = {0, 0, 0, 0, 0, 0, {0, 0}};
         const uint32_t seq = seq0 + threadIdx.x;
@@ -238,7 +246,7 @@ __global__ __launch_bounds__(SYNC_TPB) void mj_k_entropy_sync(MjDeviceBatch b) {
 
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
-    const MjScanCtx cx = make_ctx(b, im);
+    const MjScanCtx cx = make_ctx(b, im, s_pairs);
     int32_t *acc = lds_dc(b) + wave * 64 * MJ_MAX_COMP + lane;
 
     /* cold pass: the lane's subsequences back to back from a cold state at its first
@@ -324,9 +332,10 @@ __global__ __launch_bounds__(FIX_TPB) void mj_k_entropy_fix(MjDeviceBatch b) {
     const uint32_t S = im.sub_bits, SQ = MJ_SEQ_LANES * im.lane_subs;
     const Geo g = interval_geo(b.ivl_start + im.ivl_off, iv, S, SQ);
     const uint32_t seq_first = im.seq_off + b.ivl_seq[im.ivl_off + iv]; /* global slot of the interval's first sequence */
-    load_tables(b, im);
+    unsigned char *s_pairs = lds_after_dc(b, FIX_TPB / 64);
+    load_tables(b, im, s_pairs);
     __syncthreads();
-    const MjScanCtx cx = make_ctx(b, im);
+    const MjScanCtx cx = make_ctx(b, im, s_pairs);
     int32_t *fix_acc = lds_dc(b) + (threadIdx.x >> 6) * 64 * MJ_MAX_COMP + (threadIdx.x & 63);
     MjSubRec *rec = b.rec + im.rec_off + (uint64_t) b.ivl_seq[im.ivl_off + iv] * SQ;
 
@@ -446,7 +455,7 @@ __global__ __launch_bounds__(FIX_TPB) void mj_k_entropy_fix(MjDeviceBatch b) {
 constexpr int BLK_STRIDE = 128;   /* bytes per lane block buffer (unpadded: LDS capacity decides the occupancy here) */
 
 __global__ __launch_bounds__(TPB) void mj_k_entropy_write(MjDeviceBatch b) {
-    /* dynamic LDS: [tables][slots][DC accumulators][block buffers: TPB x 128 B][flush lists: TPB x (4 + 4) B] */
+    /* dynamic LDS: [tables][DC accumulators][block buffers: TPB x 128 B][flush lists: TPB x (4 + 4) B] */
     unsigned char *s_blk = lds_after_dc(b, WAVES);
     uint32_t *s_list_blk = reinterpret_cast<uint32_t *>(s_blk + TPB * BLK_STRIDE);
     uint32_t *s_list_lane = s_list_blk + TPB;
@@ -458,7 +467,7 @@ __global__ __launch_bounds__(TPB) void mj_k_entropy_write(MjDeviceBatch b) {
     const uint32_t n_seq = b.dyn[ii].n_seq;
     const uint32_t seq0 = (grp - im.wg_first) * MJ_WG_SEQS + part * WAVES;
     if (seq0 >= n_seq) return;
-    load_tables(b, im);
+    load_tables(b, im, nullptr);
     {   /* zero the block buffers */
         uint4 *z = reinterpret_cast<uint4 *>(s_blk);
         for (uint32_t i = threadIdx.x; i < TPB * BLK_STRIDE / 16; i += TPB) z[i] = make_uint4(0, 0, 0, 0);
@@ -474,7 +483,7 @@ __global__ __launch_bounds__(TPB) void mj_k_entropy_write(MjDeviceBatch b) {
     const uint32_t first = b.seq_sub[im.seq_off + seq];
     const Geo g = interval_geo(b.ivl_start + im.ivl_off, iv, S, SQ);
     const uint32_t n = min(g.nsub - first, SQ);
-    const MjScanCtx cx = make_ctx(b, im);
+    const MjScanCtx cx = make_ctx(b, im, nullptr);
     /* the lane's subsequences: u0 .. u0 + cnt - 1 of the sequence */
     const uint32_t u0 = lane * G;
     const bool valid = u0 < n;
@@ -572,9 +581,9 @@ __global__ __launch_bounds__(TPB) void mj_k_entropy_write(MjDeviceBatch b) {
 __global__ __launch_bounds__(TPB) void mj_k_entropy_serial(MjDeviceBatch b) {
     const uint32_t ii = blockIdx.x;
     const MjImageDev &im = b.img[ii];
-    load_tables(b, im);
+    load_tables(b, im, nullptr);
     __syncthreads();
-    const MjScanCtx cx = make_ctx(b, im);
+    const MjScanCtx cx = make_ctx(b, im, nullptr);
     const uint32_t *ivl = b.ivl_start + im.ivl_off;
     const uint32_t n_blocks = im.n_mcu * im.bpm;
     for (uint32_t iv = threadIdx.x; iv < im.n_ivl; iv += TPB) {
@@ -589,7 +598,7 @@ __global__ __launch_bounds__(TPB) void mj_k_entropy_serial(MjDeviceBatch b) {
         while (L.p < end && blk < blk_end) {
             mj_refill(cx, L);
             const uint32_t at = blk;
-            const MjSym s = mj_step<true>(cx, L, acc, 64, blk);
+            const MjSym s = mj_step<true>(cx, L, acc, 64, blk, 0);
             if (s.store) cx.coefs[(uint64_t) at * 64 + s.kpos] = (int16_t) s.val;
         }
     }
@@ -604,14 +613,16 @@ static size_t table_lds(const MjDeviceBatch &b, uint32_t waves) {
 hipError_t mj_launch_entropy(const MjDeviceBatch &b, hipStream_t s) {
     if (b.n_entropy_wg == 0) return hipSuccess;
     static const size_t pad = getenv("MJ_TUNE_LDS_PAD") ? (size_t) atol(getenv("MJ_TUNE_LDS_PAD")) : 0;   /* occupancy experiments */
-    const size_t lds = table_lds(b, SYNC_WAVES) + SYNC_WAVES * sizeof(SeqGeo) + 4 * sizeof(uint32_t) + 2 * SYNC_TPB * sizeof(uint2) + pad;
+    const size_t lds = table_lds(b, SYNC_WAVES) + SYNC_WAVES * sizeof(SeqGeo) + 4 * sizeof(uint32_t) + 2 * SYNC_TPB * sizeof(uint2) +
+                       (size_t) b.max_ntab * sizeof(MjHuffPair) + pad;
     hipLaunchKernelGGL(mj_k_entropy_sync, dim3(b.n_entropy_wg), dim3(SYNC_TPB), lds, s, b);
     return hipGetLastError();
 }
 
 hipError_t mj_launch_entropy_fix(const MjDeviceBatch &b, hipStream_t s) {
     if (b.n_multi_cap == 0 || b.n_entropy_wg == 0) return hipSuccess;
-    hipLaunchKernelGGL(mj_k_entropy_fix, dim3(b.n_multi_cap), dim3(FIX_TPB), table_lds(b, FIX_TPB / 64), s, b);
+    hipLaunchKernelGGL(mj_k_entropy_fix, dim3(b.n_multi_cap), dim3(FIX_TPB),
+                       table_lds(b, FIX_TPB / 64) + (size_t) b.max_ntab * sizeof(MjHuffPair), s, b);
     return hipGetLastError();
 }
 

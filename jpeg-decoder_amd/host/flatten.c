@@ -121,9 +121,10 @@ void mj_parsed_free(MjParsed *p) {
     memset(p, 0, sizeof *p);
 }
 
-void mj_flatten_huff(const HuffTable *ht, int is_ac, MjHuffDev *out, MjHuffWalk *walk) {
+void mj_flatten_huff(const HuffTable *ht, int is_ac, MjHuffDev *out, MjHuffWalk *walk, MjHuffPair *pair) {
     memset(out, 0, sizeof *out);
     memset(walk, 0, sizeof *walk);
+    memset(pair, 0, sizeof *pair);
     walk->maxcode[0] = -1;
     int nvals = 0;
     uint32_t nsub = 0;
@@ -182,6 +183,35 @@ void mj_flatten_huff(const HuffTable *ht, int is_ac, MjHuffDev *out, MjHuffWalk 
     for (uint32_t t = 0; t < MJ_SUB_MAX; t++) {
         for (uint32_t j = 0; j < MJ_SUB_SIZE; j++) {
             if (out->sub[t][j] == 0) out->sub[t][j] = none;
+        }
+    }
+    if (!is_ac) {
+        return;
+    }
+    /* runs of whole symbols inside one first-level index (see MjHuffPair) */
+    for (uint32_t idx = 0; idx < MJ_LUT_SIZE; idx++) {
+        uint32_t pos = 0, n = 0, used = 0, before = 0, last = 0, steps = 0;
+        while (pos < MJ_LUT_BITS) {
+            const uint32_t e = out->lut[(idx << pos) & (MJ_LUT_SIZE - 1)];
+            const uint32_t len = MJ_E_LEN(e);
+            if (len == 0 || len > MJ_LUT_BITS - pos) {
+                break;   /* a longer code, or one whose bits are not all known */
+            }
+            if (n >= 1 && steps > 15) {
+                break;
+            }
+            before = steps;
+            last = e & 127u;
+            steps += last;
+            used = pos + len + ((e >> 7) & 15u);
+            pos = used;
+            n++;
+            if (last == 64) {
+                break;   /* end of block: what follows belongs to the next block */
+            }
+        }
+        if (n >= 2 && used <= 31) {
+            pair->pair[idx] = (uint16_t) ((used << 11) | (before << 7) | last);
         }
     }
 }
@@ -298,12 +328,12 @@ int mj_flatten_image(const MjParsed *p, size_t file_len, MjImageDev *img, MjHuff
         }
         if (dc_slot[td] < 0) {
             dc_slot[td] = (int) set->ntab;
-            mj_flatten_huff(&p->hts.DCAC[TC_DC][td], 0, &set->tab[set->ntab], &set->walk[set->ntab]);
+            mj_flatten_huff(&p->hts.DCAC[TC_DC][td], 0, &set->tab[set->ntab], &set->walk[set->ntab], &set->pair[set->ntab]);
             set->ntab++;
         }
         if (ac_slot[ta] < 0) {
             ac_slot[ta] = (int) set->ntab;
-            mj_flatten_huff(&p->hts.DCAC[TC_AC][ta], 1, &set->tab[set->ntab], &set->walk[set->ntab]);
+            mj_flatten_huff(&p->hts.DCAC[TC_AC][ta], 1, &set->tab[set->ntab], &set->walk[set->ntab], &set->pair[set->ntab]);
             set->ntab++;
         }
         const Component *c = &fh->cs[ci];
