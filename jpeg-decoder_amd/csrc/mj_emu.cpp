@@ -238,6 +238,7 @@ int64_t mj_emu_decode_coefs(const uint8_t *file, size_t len, int16_t *coefs, int
                 MjLane L;
                 mj_lane_init(cx, L, p, k, c);
                 while (mj_write_live(L.p, L.k, skip, end, b1)) {
+                    mj_checkpoint(cx, L);
                     bool fin = false;
                     uint32_t fin_blk = 0;
                     mj_write_step(cx, L, skip, blk, blk_end, d, 1, buf, fin, fin_blk);

@@ -134,16 +134,27 @@ MJ_HD MjQuad mj_load_quad(const MjScanCtx &cx, uint32_t block) {
     return q;
 }
 
+/* How often mj_checkpoint must run: at least once every this many symbols.  A symbol
+ * takes at most one word from the queue, and the queue holds eight. */
+#define MJ_CHECK_EVERY 4
+
 /* Decoder state of one lane.  (p, k, c) is the state proper -- equal (p, k, c)
- * decode identically from there on; the rest is derived from it. */
+ * decode identically from there on; the rest is derived from it.
+ *
+ * Stream words reach the window through a queue of three 16-byte blocks: qa and qb
+ * are complete and are what mj_refill takes words from; qc is in flight.  Loads are
+ * issued only in mj_checkpoint, which the caller runs every few symbols for the whole
+ * wavefront at once: the memory counter a wavefront waits on is in order, so a load
+ * issued for one lane between two symbols would stall every lane that needs its own,
+ * older data in the next one. */
 struct MjLane {
     uint32_t hi, lo;    /* the stream from bit p on, left-aligned in hi:lo, zero beyond the window */
     uint32_t p;         /* bit offset of the next symbol */
     uint32_t thr;       /* the window ends at bit thr + 32: more than 32 bits are left while p < thr */
-    MjQuad cur;         /* the 16-byte block the next word comes from */
-    uint32_t icur;      /* index (0..3) of that word */
-    MjQuad nxt;         /* the following 16 bytes, requested one block ahead */
-    uint32_t blk16;     /* index of the 16-byte block held in nxt */
+    MjQuad qa, qb;      /* the 32 bytes the next words come from */
+    uint32_t icur;      /* index (0..7) of the next word in qa:qb */
+    MjQuad qc;          /* the following 16 bytes, requested at a checkpoint */
+    uint32_t blk16;     /* index of the 16-byte block held in qc */
     uint32_t k;         /* zigzag index of the next coefficient; 0: the DC symbol comes next */
     uint32_t c;         /* block slot inside the MCU */
     uint32_t slot;      /* mj_slot_of(c) */
@@ -151,29 +162,41 @@ struct MjLane {
     uint32_t pcur;      /* byte offset of the MjHuffPair of the slot's AC table */
 };
 
+MJ_HD uint32_t mj_pick4(const MjQuad &q, bool b0, bool b1) {
+    const uint32_t x = b0 ? q.w1 : q.w0, y = b0 ? q.w3 : q.w2;
+    return b1 ? y : x;
+}
+
 /* next stream word, byte-swapped to bit order */
-MJ_HD uint32_t mj_take_word(const MjScanCtx &cx, MjLane &L) {
+MJ_HD uint32_t mj_take_word(MjLane &L) {
     const uint32_t i = L.icur;
-    const uint32_t lo2 = (i & 1u) ? L.cur.w1 : L.cur.w0, hi2 = (i & 1u) ? L.cur.w3 : L.cur.w2;
-    const uint32_t w = mj_be32((i & 2u) ? hi2 : lo2);
+    const bool b0 = (i & 1u) != 0, b1 = (i & 2u) != 0;
+    const uint32_t a = mj_pick4(L.qa, b0, b1), b = mj_pick4(L.qb, b0, b1);
     L.icur = i + 1;
-    if (L.icur == 4) {
-        L.cur = L.nxt;
-        L.icur = 0;
+    return mj_be32((i & 4u) ? b : a);
+}
+
+/* Keep the queue ahead of the window: once qa is used up, move on by 16 bytes and
+ * request the next block. */
+MJ_HD void mj_checkpoint(const MjScanCtx &cx, MjLane &L) {
+    if (L.icur >= 4) {
+        L.qa = L.qb;
+        L.qb = L.qc;
+        L.icur -= 4;
         L.blk16++;
-        L.nxt = mj_load_quad(cx, L.blk16);   /* not touched for another four words */
+        L.qc = mj_load_quad(cx, L.blk16);
     }
-    return w;
 }
 
 MJ_HD void mj_lane_init(const MjScanCtx &cx, MjLane &L, uint32_t p, uint32_t k, uint32_t c) {
     const uint32_t wi = p >> 5, sh = p & 31u;
     L.blk16 = wi >> 2;
-    L.cur = mj_load_quad(cx, L.blk16);
-    L.blk16++;
-    L.nxt = mj_load_quad(cx, L.blk16);
+    L.qa = mj_load_quad(cx, L.blk16);
+    L.qb = mj_load_quad(cx, L.blk16 + 1);
+    L.blk16 += 2;
+    L.qc = mj_load_quad(cx, L.blk16);
     L.icur = wi & 3u;
-    const uint32_t w0 = mj_take_word(cx, L), w1 = mj_take_word(cx, L);
+    const uint32_t w0 = mj_take_word(L), w1 = mj_take_word(L);
     L.hi = sh ? mj_align(w0, w1, 32u - sh) : w0;
     L.lo = w1 << sh;
     L.p = p;
@@ -186,9 +209,9 @@ MJ_HD void mj_lane_init(const MjScanCtx &cx, MjLane &L, uint32_t p, uint32_t k, 
 }
 
 /* Top the window up to more than 32 bits. */
-MJ_HD void mj_refill(const MjScanCtx &cx, MjLane &L) {
+MJ_HD void mj_refill(MjLane &L) {
     if (L.p >= L.thr) {
-        const uint32_t w = mj_take_word(cx, L);
+        const uint32_t w = mj_take_word(L);
         const uint32_t sh = L.p - L.thr;           /* 0..31: 32 - sh bits are left */
         L.hi |= (w >> 1) >> (31u - sh);
         L.lo = w << sh;
@@ -311,8 +334,12 @@ MJ_HD MjSym mj_step(const MjScanCtx &cx, MjLane &L, int32_t *acc, uint32_t strid
  * added to its component's accumulator.  The lane can go on to the next span as it is.
  */
 MJ_HD void mj_run_span(const MjScanCtx &cx, MjLane &L, uint32_t end, uint32_t &nb, int32_t *acc, uint32_t stride) {
+    uint32_t it = 0;
     while (L.p < end) {
-        mj_refill(cx, L);
+        if ((it++ % MJ_CHECK_EVERY) == 0) {
+            mj_checkpoint(cx, L);
+        }
+        mj_refill(L);
         (void) mj_step<false>(cx, L, acc, stride, nb, end);
     }
 }
@@ -340,11 +367,12 @@ MJ_HD void mj_decode_span(const MjScanCtx &cx, uint32_t &p, uint32_t &k, uint32_
  * entry state is in the middle of a block (k != 0) runs in `skip` mode until that
  * block ends -- the previous lane finishes it by decoding past its own subsequence
  * end (see mj_write_live) -- so every block is assembled by exactly one lane and
- * leaves the chip as one full 128-byte line.  acc holds the DC predictors.
+ * leaves the chip as one full 128-byte line.  acc holds the DC predictors.  The caller
+ * runs mj_checkpoint at least every MJ_CHECK_EVERY steps.
  */
 MJ_HD void mj_write_step(const MjScanCtx &cx, MjLane &L, bool &skip, uint32_t &blk, uint32_t blk_end, int32_t *acc,
                          uint32_t stride, int16_t *blkbuf, bool &fin, uint32_t &fin_blk) {
-    mj_refill(cx, L);
+    mj_refill(L);
     uint32_t ended = 0;
     const MjSym s = mj_step<true>(cx, L, acc, stride, ended, 0);
     const bool mine = !skip && blk < blk_end;

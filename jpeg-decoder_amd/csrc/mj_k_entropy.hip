@@ -543,9 +543,10 @@ __global__ __launch_bounds__(TPB) void mj_k_entropy_write(MjDeviceBatch b) {
     MjLane L;
     bool live = valid && mj_write_live(p, k, skip, end, g.b1);
     if (live) mj_lane_init(cx, L, p, k, c);
-    while (__any(live)) {
+    for (uint32_t it = 0; __any(live); it++) {
         bool fin = false;
         uint32_t fin_blk = 0;
+        if (live && (it % MJ_CHECK_EVERY) == 0) mj_checkpoint(cx, L);
         if (live) {
             mj_write_step(cx, L, skip, blk, blk_end, acc, 64, blkbuf, fin, fin_blk);
             live = mj_write_live(L.p, L.k, skip, end, g.b1);
@@ -596,7 +597,8 @@ __global__ __launch_bounds__(TPB) void mj_k_entropy_serial(MjDeviceBatch b) {
         int32_t *acc = lds_dc(b) + (threadIdx.x >> 6) * 64 * MJ_MAX_COMP + (threadIdx.x & 63);
         acc[0] = acc[64] = acc[128] = acc[192] = 0;
         while (L.p < end && blk < blk_end) {
-            mj_refill(cx, L);
+            mj_checkpoint(cx, L);
+            mj_refill(L);
             const uint32_t at = blk;
             const MjSym s = mj_step<true>(cx, L, acc, 64, blk, 0);
             if (s.store) cx.coefs[(uint64_t) at * 64 + s.kpos] = (int16_t) s.val;
