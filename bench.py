@@ -71,11 +71,11 @@ def _cpu_worker(args):
     return t
 
 
-def cpu_baseline(files, width, height, max_cores=16, iters=2):
+def cpu_baseline(files, width, height, max_cores=16, iters=64):
     """The reference (oracle/_ref, compiled from its unmodified sources) -- or, where
     that library is absent, the CPU restatement -- timed headless on the host cores:
     one process per core, each decoding its own image `iters` times (decode + colour,
-    file already in memory)."""
+    file already in memory).  64 decodes of a 4K image per core are about ten seconds."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from refbind import Oracle, Ref
     kind = "reference" if Ref.available() else ("port" if Oracle.available() else None)
@@ -100,6 +100,22 @@ def cpu_baseline(files, width, height, max_cores=16, iters=2):
             "per_core": round(value / cores, 2),
             "sample": f"{cores} processes x {iters} decodes of one {width}x{height} image each "
                       f"({mp_total:.0f} MP, pool wall {wall:.1f} s incl. start-up)"}
+
+
+def measured_traffic(kernel, workload, batch):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 counter passes
+    (profiles/traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate runs of this
+    benchmark; reads doubled as gfx950's FETCH_SIZE counts 128-byte requests as 64).  None
+    when no measurement for this workload and batch size is on file."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            t = json.load(f)
+    except (OSError, ValueError):
+        return None
+    for e in t.get("entries", []):
+        if e.get("kernel") == kernel and e.get("workload") == workload and e.get("batch") == batch:
+            return int((2 * e["fetch_size_kb"] + e["write_size_kb"]) * 1024)
+    return None
 
 
 def parity_check(batch, files, idx=0):
@@ -275,7 +291,7 @@ def main():
                        "streams": n_streams},
             "roofline": {"kernel": "mj_k_idct_colour", "bound": "hbm", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": None,
+                         "traffic": measured_traffic("mj_k_idct_colour", args.workload, args.batch // n_streams),
                          "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(k_avg_ms, 4)},
             "entropy": {"kernel": "mj_k_entropy_sync (+fix/write)", "avg_launch_ms": round(e_avg_ms, 4),
                         "decoded_Gbit_per_s": round(8.0 * comp_bytes_rank / n_streams / (e_avg_ms * 1e-3) / 1e9, 2) if e_avg_ms else None,

@@ -92,12 +92,14 @@ __device__ __forceinline__ void idct8(float &d0, float &d1, float &d2, float &d3
     d7 = (float) (C * (double) (W0 - W7));
 }
 
-/* dct.c:187-193 with CLAMP_8 (dct.c:6): clamp(0.25*x + 128) in double, then
- * truncate.  q is 0.25*x already (see idct8<true>).  Truncating first and clamping
- * the integer gives the same result for every finite input. */
+/* dct.c:187-193 with CLAMP_8 (dct.c:6): clamp(0.25*x + 128) in double, then truncate.
+ * q is 0.25*x already (see idct8<true>).  q + 128 is exact in double, and for a sum
+ * that is not negative truncation is floor(q) + 128; a negative sum clamps to 0 either
+ * way.  So the double arithmetic reduces, bit for bit, to a float floor, a clamp to
+ * [-128, 127] (which also keeps the integer conversion in range) and an integer add. */
 __device__ __forceinline__ uint32_t finish(float q) {
-    const int32_t i = (int32_t) ((double) q + 128.0);
-    return (uint32_t) min(max(i, 0), 255);
+    const float f = fminf(fmaxf(floorf(q), -128.0f), 127.0f);
+    return (uint32_t) ((int32_t) f + 128);
 }
 
 /* colour_conversion.c:76-79 as compiled by gcc 11.4 -O2: below zero -> 0, above

@@ -9,13 +9,18 @@ tag=${1:-prof}
 out=gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
-B="bench.py --steps 10 --warmup 2 --no-cpu-baseline --gen-workers 1"
+# the profiled command: the default benchmark minus the CPU leg and the forked input generation
+# (the profiler preload does not survive forks)
+B="bench.py --steps 20 --warmup 3 --no-cpu-baseline --gen-workers 1"
 timeout -k 10 300 python3 -u bench.py --steps 20 --warmup 3 > "$out/bench.json" 2> "$out/bench.err" &&
-timeout -k 10 200 rocprofv3 --kernel-trace --stats -d "$out/stats" -o run -- python3 $B > "$out/stats.log" 2>&1 &&
-timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d "$out/pmc_fetch" -o run -- python3 $B > "$out/pmc_fetch.log" 2>&1 &&
-timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d "$out/pmc_write" -o run -- python3 $B > "$out/pmc_write.log" 2>&1 &&
-timeout -s KILL 200 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY -d "$out/pmc_sq" -o run -- python3 $B > "$out/pmc_sq.log" 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o run -- python3 $B > "$out/stats.log" 2>&1 &&
+timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -o run -- python3 $B > "$out/pmc_fetch.log" 2>&1 &&
+timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -o run -- python3 $B > "$out/pmc_write.log" 2>&1 &&
+timeout -s KILL 200 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d "$out/pmc_sq" -o run -- python3 $B > "$out/pmc_sq.log" 2>&1
 rc=$?
+python3 profiles/pmc_summary.py "$out/pmc_fetch" "$out/pmc_write" "$out/pmc_sq" > "$out/pmc_summary.txt" 2>&1
+find "$out" -name "*_kernel_trace.csv" -delete    # per-dispatch rows: large, the stats file has the averages
+find "$out" -name "*_counter_collection.csv" -delete
 echo "collect rc=$rc"
 ls -R "$out" | head -40
 exit $rc
