@@ -75,9 +75,9 @@ hipError_t mj_launch_entropy_serial(const MjDeviceBatch &b, hipStream_t s);
 hipError_t mj_launch_idct_colour(const MjDeviceBatch &b, hipStream_t s);
 
 /* tile geometry of the IDCT kernel for one image (host + device) */
-#define MJ_IDCT_THREADS 256
+#define MJ_IDCT_THREADS 512
 #define MJ_IDCT_MAX_BLOCKS 256
-/* MCUs per tile: at most MJ_IDCT_MAX_BLOCKS blocks, one per thread. */
+/* MCUs per tile: at most MJ_IDCT_MAX_BLOCKS blocks (eight lanes work on a block, 64 blocks per pass). */
 static inline __host__ __device__ uint32_t mj_idct_tile_cap(uint32_t bpm, uint32_t hmax) {
     (void) hmax;
     uint32_t tmax = MJ_IDCT_MAX_BLOCKS / bpm;

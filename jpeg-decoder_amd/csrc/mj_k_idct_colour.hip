@@ -12,9 +12,13 @@
  * (luma and chroma of the same pixels sit next to each other), so the tile is one
  * contiguous run of T*bpm*128 bytes:
  *   1. the workgroup copies it to LDS with 16-byte coalesced loads;
- *   2. each thread takes one 8x8 block: de-zigzag + dequantise (int16 wrap) into
- *      registers, sixteen 8-point butterflies, level shift, clamp, truncate, and
- *      stores the 64 samples into the tile's component planes in LDS;
+ *   2. eight lanes share one 8x8 block, 64 blocks per pass: lane r de-zigzags and
+ *      dequantises row r (int16 wrap), runs the row butterfly, the eight lanes
+ *      transpose through LDS, lane x runs the column butterfly, they transpose back,
+ *      and lane r level-shifts, clamps, truncates and stores row r of the samples
+ *      over the block's own coefficients.  A lane holds eight values, not sixty-four:
+ *      the kernel runs at six wavefronts per SIMD instead of three, which is what
+ *      keeps HBM busy while other wavefronts are in the butterflies;
  *   3. the workgroup walks the tile's pixel rows: nearest-neighbour chroma lookup,
  *      colour transform, clamp, and 12-byte (4-pixel) coalesced stores of RGB24.
  *
@@ -30,15 +34,14 @@ namespace {
 
 constexpr int TPB = MJ_IDCT_THREADS;
 constexpr int MAXB = MJ_IDCT_MAX_BLOCKS;
-constexpr int COEF_STRIDE = 144;               /* bytes per block in LDS: 128 + 16 pad, conflict-free b128 reads */
-constexpr int PLANE_BYTES = MAXB * 64;         /* every sample of every block of the tile, all components */
+constexpr int COEF_STRIDE = 136;               /* bytes per block in LDS: 128 + 8, spreads the 2-byte de-zigzag reads over the banks */
+constexpr int TR_GROUP = 72;                   /* floats per 8x8 transpose buffer: 64 + 8, conflict-free strided access */
+constexpr int TR_BYTES = (TPB / 8) * TR_GROUP * 4;
 
-/* compile-time zigzag table for fully unrolled register indexing */
-struct ZZ {
-    static constexpr int v[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
-                                  41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
-                                  30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
-};
+/* zigzag position of natural-order coefficient n (inverse of quant_table.c:25-34) */
+__constant__ uint8_t c_zzinv[64] = {0,  1,  5,  6,  14, 15, 27, 28, 2,  4,  7,  13, 16, 26, 29, 42, 3,  8,  12, 17, 25, 30,
+                                    41, 43, 9,  11, 18, 24, 31, 40, 44, 53, 10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38,
+                                    46, 51, 55, 60, 21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63};
 
 /* 8-point inverse butterfly (dct.c:296-341).  (float)(C * (double)x) is a product
  * rounded to double and then to float, as the C source's mixed types imply.
@@ -145,17 +148,28 @@ __device__ __forceinline__ void store_quad(uint8_t *o, const uint32_t px[4], uin
     }
 }
 
+#ifndef MJ_IDCT_WAVES
+#define MJ_IDCT_WAVES 6
+#endif
+
+/* Where the samples of the tile live after the butterflies: block `blk` of the tile
+ * keeps its 8x8 bytes, row-major, in the first 64 bytes of its LDS slot. */
+__device__ __forceinline__ uint32_t sample_off(uint32_t blk, uint32_t x, uint32_t y) {
+    return blk * COEF_STRIDE + (y & 7u) * 8u + (x & 7u);
+}
+
 /*
  * Colour stage for the common layouts: luma at full resolution, both chroma
- * components subsampled by 2^SH horizontally and 2^SV vertically (4:4:4, 4:2:2,
- * 4:2:0, 4:4:0, 4:1:1).  A thread converts a patch of 4 x 2^SV pixels per step, so
- * every chroma sample and its two table rows are fetched once per patch.
+ * components subsampled by 2^SH horizontally and 2^SV vertically with one block each
+ * per MCU (4:4:4, 4:2:2, 4:2:0, 4:4:0, 4:1:1).  A thread converts a patch of
+ * 4 x 2^SV pixels per step, so every chroma sample and its two table rows are fetched
+ * once per patch.  s0, s1, s2: first block slot of each component inside the MCU.
  */
 template <int SH, int SV>
-__device__ __forceinline__ void colour_fast(const uint8_t *s_plane, const double2 *s_tcb, const double2 *s_tcr,
-                                            uint32_t po1, uint32_t po2, uint32_t pw0, uint32_t pwc, uint32_t tile_w,
-                                            uint32_t tile_h, uint32_t px0, uint32_t py0, uint32_t X, uint32_t Y,
-                                            uint32_t pitch, uint8_t *rgb) {
+__device__ __forceinline__ void colour_fast(const uint8_t *s_smp, const double2 *s_tcb, const double2 *s_tcr, uint32_t bpm,
+                                            uint32_t s0, uint32_t s1, uint32_t s2, uint32_t tile_w, uint32_t tile_h,
+                                            uint32_t px0, uint32_t py0, uint32_t X, uint32_t Y, uint32_t pitch,
+                                            uint8_t *rgb) {
     constexpr int NC = 4 >> SH, ROWS = 1 << SV;
     const uint32_t quads = tile_w / 4, prow_n = tile_h >> SV;
     const uint32_t dy = TPB / quads, dq = TPB - dy * quads;
@@ -170,9 +184,11 @@ __device__ __forceinline__ void colour_fast(const uint8_t *s_plane, const double
         const uint32_t x = qx * 4, gx = px0 + x;
         const uint32_t y = pr << SV, gy = py0 + y;
         if (gy >= Y || gx >= X) continue;
-        /* chroma samples of the patch and their product rows */
-        const uint8_t *cbp = s_plane + po1 + pr * pwc + (x >> SH);
-        const uint8_t *crp = s_plane + po2 + pr * pwc + (x >> SH);
+        /* chroma samples of the patch and their product rows: chroma pixel (x >> SH, pr)
+         * of MCU x >> (3 + SH) */
+        const uint32_t cx = x >> SH, mcu = x >> (3 + SH);
+        const uint8_t *cbp = s_smp + sample_off(mcu * bpm + s1, cx, pr);
+        const uint8_t *crp = s_smp + sample_off(mcu * bpm + s2, cx, pr);
         uint32_t cbw, crw;
         if (SH == 0) {
             cbw = *reinterpret_cast<const uint32_t *>(cbp);
@@ -190,10 +206,14 @@ __device__ __forceinline__ void colour_fast(const uint8_t *s_plane, const double
             tb[i] = s_tcb[(cbw >> (8 * i)) & 0xFFu];
             tr[i] = s_tcr[(crw >> (8 * i)) & 0xFFu];
         }
+        /* luma block: column (x >> 3) & (2^SH - 1), row r >> 3 of the MCU's luma blocks */
+        const uint32_t lcol = (x >> 3) & ((1u << SH) - 1u);
 #pragma unroll
         for (int r = 0; r < ROWS; r++) {
             if (gy + r >= Y) break;
-            const uint32_t yw = *reinterpret_cast<const uint32_t *>(s_plane + (y + r) * pw0 + x);
+            const uint32_t ly = y + r;
+            const uint32_t lblk = mcu * bpm + s0 + ((ly >> 3) << SH) + lcol;
+            const uint32_t yw = *reinterpret_cast<const uint32_t *>(s_smp + sample_off(lblk, x, ly));
             uint32_t px[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -204,20 +224,16 @@ __device__ __forceinline__ void colour_fast(const uint8_t *s_plane, const double
     }
 }
 
-#ifndef MJ_IDCT_WAVES
-#define MJ_IDCT_WAVES 3
-#endif
 __global__ __launch_bounds__(TPB, MJ_IDCT_WAVES) void mj_k_idct_colour(MjDeviceBatch b) {
-    /* One LDS region used twice: first the tile's coefficients (144 B per block),
-     * then -- once every thread holds its block in registers -- the tile's sample
-     * planes (64 B per block) followed by the two chroma product tables. */
-    __shared__ __align__(16) uint8_t s_mem[MAXB * COEF_STRIDE];
+    /* LDS: the tile's blocks (coefficients, then -- in place -- samples); the transpose
+     * buffers of the butterflies, which later hold the two chroma product tables; the
+     * quantiser tables */
+    __shared__ __align__(16) uint8_t s_blk[MAXB * COEF_STRIDE];
+    __shared__ __align__(16) uint8_t s_tr[TR_BYTES];
     __shared__ __align__(16) uint16_t s_qt[MJ_MAX_COMP][64];
-    uint8_t *s_coef = s_mem;
-    uint8_t *s_plane = s_mem;
-    double2 *s_tcb = reinterpret_cast<double2 *>(s_mem + PLANE_BYTES);
+    double2 *s_tcb = reinterpret_cast<double2 *>(s_tr);
     double2 *s_tcr = s_tcb + 256;
-    static_assert(PLANE_BYTES + 2 * 256 * sizeof(double2) <= MAXB * COEF_STRIDE, "LDS reuse");
+    static_assert(2 * 256 * sizeof(double2) <= TR_BYTES, "chroma tables reuse the transpose buffers");
 
     const uint32_t ii = b.idct_wg_img[blockIdx.x];
     const MjImageDev &im = b.img[ii];
@@ -234,96 +250,115 @@ __global__ __launch_bounds__(TPB, MJ_IDCT_WAVES) void mj_k_idct_colour(MjDeviceB
     const uint4 *src = reinterpret_cast<const uint4 *>(b.coefs + (im.coef_off + ((uint64_t) mrow * im.mcus_x + m0) * bpm) * 64);
     for (uint32_t i = threadIdx.x; i < nblk * 8; i += TPB) {
         const uint4 v = src[i];
-        *reinterpret_cast<uint4 *>(s_coef + (i >> 3) * COEF_STRIDE + (i & 7) * 16) = v;
+        uint2 *d = reinterpret_cast<uint2 *>(s_blk + (i >> 3) * COEF_STRIDE + (i & 7) * 16);
+        d[0] = make_uint2(v.x, v.y);
+        d[1] = make_uint2(v.z, v.w);
     }
     for (uint32_t i = threadIdx.x; i < im.ncs * 64; i += TPB) {
         s_qt[i >> 6][i & 63] = im.qt[i >> 6][i & 63];
     }
     __syncthreads();
 
-    /* plane layout inside s_plane: component c occupies rows of width w_c = nm*hsf*8,
-     * height vsf*8, one after the other (scalars + selects: no indexed arrays) */
-    const uint32_t pw0 = nm * im.comp[0].hsf * 8;
-    const uint32_t pw1 = (im.ncs > 1) ? nm * im.comp[1].hsf * 8 : 0;
-    const uint32_t pw2 = (im.ncs > 2) ? nm * im.comp[2].hsf * 8 : 0;
-    const uint32_t po0 = 0;
-    const uint32_t po1 = pw0 * im.comp[0].vsf * 8;
-    const uint32_t po2 = po1 + ((im.ncs > 1) ? pw1 * im.comp[1].vsf * 8 : 0);
-    auto pl_w = [&](uint32_t c) { return c == 0 ? pw0 : (c == 1 ? pw1 : pw2); };
-    auto pl_off = [&](uint32_t c) { return c == 0 ? po0 : (c == 1 ? po1 : po2); };
-
-    /* ---- 2. one block per thread ------------------------------------------ */
-    const bool has_block = threadIdx.x < nblk;
-    uint32_t zw[32];
-    if (has_block) {
-        const uint4 *cz = reinterpret_cast<const uint4 *>(s_coef + threadIdx.x * COEF_STRIDE);
+    /* ---- 2. eight lanes per block, 64 blocks per pass ---------------------- */
+    if (!(b.dbg & 16u)) {
+        const uint32_t r = threadIdx.x & 7u;                 /* the lane's row, then column, then row again */
+        const uint32_t grp = threadIdx.x >> 3;               /* block within the pass */
+        float *tr = reinterpret_cast<float *>(s_tr) + grp * TR_GROUP;
+        /* zigzag positions of the coefficients of row r */
+        const uint2 zr = reinterpret_cast<const uint2 *>(c_zzinv)[r];
+        /* the reference scales the first row and the first column by 1/sqrt(2) before the
+         * butterflies (dct.c:164-167), the corner twice: lane 0 scales its whole row, the
+         * others multiply by one, which changes nothing */
+        const double row_scale = (r == 0) ? 0.707106781 : 1.0;
+        for (uint32_t b0 = 0; b0 < nblk; b0 += TPB / 8) {
+            const uint32_t blk = b0 + grp;
+            if (blk >= nblk) continue;                       /* whole groups of eight lanes drop out together */
+            const uint32_t slot = blk % bpm;
+            const uint32_t comp = im.blk_comp[slot];
+            uint8_t *bp = s_blk + blk * COEF_STRIDE;
+            float c[8];
+            {
+                const uint4 qv = *reinterpret_cast<const uint4 *>(&s_qt[comp][8 * r]);
+                const uint32_t qw[4] = {qv.x, qv.y, qv.z, qv.w};
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const uint4 v = cz[i];
-            zw[4 * i + 0] = v.x;
-            zw[4 * i + 1] = v.y;
-            zw[4 * i + 2] = v.z;
-            zw[4 * i + 3] = v.w;
+                for (int j = 0; j < 8; j++) {
+                    const uint32_t zi = (((j < 4) ? zr.x : zr.y) >> (8 * (j & 3))) & 0xFFu;
+                    const int32_t z = *reinterpret_cast<const int16_t *>(bp + 2 * zi);
+                    const int32_t q = (int32_t) ((j & 1) ? (qw[j >> 1] >> 16) : (qw[j >> 1] & 0xFFFFu));
+                    /* int16 wrap of the product (quant_table.c:137) */
+                    c[j] = (float) (int16_t) (z * q);
+                }
+            }
+            c[0] = (float) ((double) c[0] * 0.707106781);    /* first column */
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                c[j] = (float) ((double) c[j] * row_scale);  /* first row */
+            }
+            idct8<false>(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]);
+            /* rows -> columns (the reference transposes, runs rows again, and transposes
+             * back on the store: dct.c:173-193).  The eight lanes of a block sit in one
+             * wavefront, which runs its LDS operations in order. */
+            *reinterpret_cast<float4 *>(tr + r * 8) = make_float4(c[0], c[1], c[2], c[3]);
+            *reinterpret_cast<float4 *>(tr + r * 8 + 4) = make_float4(c[4], c[5], c[6], c[7]);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int y = 0; y < 8; y++) c[y] = tr[y * 8 + r];
+            idct8<true>(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int y = 0; y < 8; y++) tr[y * 8 + r] = c[y];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const float4 lo4 = *reinterpret_cast<const float4 *>(tr + r * 8), hi4 = *reinterpret_cast<const float4 *>(tr + r * 8 + 4);
+            const uint32_t lo = finish(lo4.x) | (finish(lo4.y) << 8) | (finish(lo4.z) << 16) | (finish(lo4.w) << 24);
+            const uint32_t hi = finish(hi4.x) | (finish(hi4.y) << 8) | (finish(hi4.z) << 16) | (finish(hi4.w) << 24);
+            /* row r of the samples, over the block's own coefficients: all eight lanes
+             * have read theirs by now */
+            *reinterpret_cast<uint2 *>(bp + r * 8) = make_uint2(lo, hi);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
     }
-    __syncthreads();   /* every block is in registers: the region becomes planes + tables */
-    {
-        const double v = (double) (float) threadIdx.x - 128.0;   /* TPB == 256 sample values */
+    __syncthreads();   /* all samples are in place; the transpose buffers are free */
+    if (threadIdx.x < 256) {
+        const double v = (double) (float) threadIdx.x - 128.0;
         s_tcb[threadIdx.x] = make_double2(0.34414 * v, 1.772 * v);
-        s_tcr[threadIdx.x] = make_double2(1.402 * v, 0.71414 * v);
+    } else if (threadIdx.x < 512) {
+        const double v = (double) (float) (threadIdx.x - 256) - 128.0;
+        s_tcr[threadIdx.x - 256] = make_double2(1.402 * v, 0.71414 * v);
     }
-    if (has_block && !(b.dbg & 16u)) {
-        const uint32_t t = threadIdx.x / bpm, slot = threadIdx.x % bpm;
-        const uint32_t comp = im.blk_comp[slot];
-        const uint16_t *q = s_qt[comp];
-        float c[64];
-#pragma unroll
-        for (int i = 0; i < 64; i++) {
-            const int n = ZZ::v[i];
-            const int32_t z = (int32_t) (int16_t) ((i & 1) ? (zw[i >> 1] >> 16) : (zw[i >> 1] & 0xFFFFu));
-            /* int16 wrap of the product (quant_table.c:137) */
-            c[n] = (float) (int16_t) (z * (int32_t) q[n]);
-        }
-        /* dct.c:164-167: first row and first column scaled; c[0] twice */
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            c[i] = (float) ((double) c[i] * 0.707106781);
-            c[8 * i] = (float) ((double) c[8 * i] * 0.707106781);
-        }
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            idct8<false>(c[8 * r + 0], c[8 * r + 1], c[8 * r + 2], c[8 * r + 3], c[8 * r + 4], c[8 * r + 5], c[8 * r + 6],
-                         c[8 * r + 7]);
-        }
-        /* second pass down the columns (the reference transposes, runs rows, and
-         * transposes back on the store: dct.c:173-193) */
-#pragma unroll
-        for (int x = 0; x < 8; x++) {
-            idct8<true>(c[x], c[8 + x], c[16 + x], c[24 + x], c[32 + x], c[40 + x], c[48 + x], c[56 + x]);
-        }
-        const uint32_t x0 = (t * im.comp[comp].hsf + im.blk_h[slot]) * 8, y0 = im.blk_v[slot] * 8u;
-        uint8_t *dst = s_plane + pl_off(comp) + y0 * pl_w(comp) + x0;
-#pragma unroll
-        for (int y = 0; y < 8; y++) {
-            uint32_t lo = finish(c[8 * y + 0]) | (finish(c[8 * y + 1]) << 8) | (finish(c[8 * y + 2]) << 16) |
-                          (finish(c[8 * y + 3]) << 24);
-            uint32_t hi = finish(c[8 * y + 4]) | (finish(c[8 * y + 5]) << 8) | (finish(c[8 * y + 6]) << 16) |
-                          (finish(c[8 * y + 7]) << 24);
-            *reinterpret_cast<uint2 *>(dst + y * pl_w(comp)) = make_uint2(lo, hi);
-        }
+    const uint8_t *s_smp = s_blk;
+
+    /* first block slot of each component inside the MCU (scan order: all blocks of a
+     * component are consecutive, decode.c:591-611) */
+    uint32_t sb0 = 0, sb1 = 0, sb2 = 0;
+    for (uint32_t i = bpm; i-- > 0;) {
+        const uint32_t cc = im.blk_comp[i];
+        if (cc == 0) sb0 = i;
+        else if (cc == 1) sb1 = i;
+        else if (cc == 2) sb2 = i;
     }
+    const uint32_t hs0 = im.comp[0].hsf, hs1 = (im.ncs > 1) ? im.comp[1].hsf : 1u, hs2 = (im.ncs > 2) ? im.comp[2].hsf : 1u;
+    /* sample (x, y) of component c, in tile coordinates of that component */
+    auto smp = [&](uint32_t sb, uint32_t hs, uint32_t x, uint32_t y) -> uint32_t {
+        const uint32_t bx = x >> 3, m = bx / hs, h = bx - m * hs;
+        return sample_off(m * bpm + sb + (y >> 3) * hs + h, x, y);
+    };
     __syncthreads();
 
     /* ---- optional: the padded component planes (Image.buf, decode.c:517-531) */
     if (b.want_planes) {
-        for (uint32_t c = 0; c < im.ncs; c++) {
-            const uint32_t w = pl_w(c), h = im.comp[c].vsf * 8;
-            uint8_t *pl = b.planes + im.comp[c].plane_off + (uint64_t) (mrow * h) * im.comp[c].pw + m0 * im.comp[c].hsf * 8;
-            for (uint32_t i = threadIdx.x; i < (w / 4) * h; i += TPB) {
-                const uint32_t y = i / (w / 4), x4 = i % (w / 4);
-                *reinterpret_cast<uint32_t *>(pl + (uint64_t) y * im.comp[c].pw + x4 * 4) =
-                    *reinterpret_cast<const uint32_t *>(s_plane + pl_off(c) + y * w + x4 * 4);
-            }
+        for (uint32_t i = threadIdx.x; i < nblk * 8; i += TPB) {
+            const uint32_t blk = i >> 3, row = i & 7u;
+            const uint32_t m = blk / bpm, slot = blk - m * bpm;
+            const uint32_t cc = im.blk_comp[slot];
+            const uint32_t hs = im.comp[cc].hsf, vs = im.comp[cc].vsf;
+            const uint64_t py = (uint64_t) mrow * vs * 8 + im.blk_v[slot] * 8u + row;
+            const uint64_t px = ((uint64_t) (m0 + m) * hs + im.blk_h[slot]) * 8;
+            *reinterpret_cast<uint2 *>(b.planes + im.comp[cc].plane_off + py * im.comp[cc].pw + px) =
+                *reinterpret_cast<const uint2 *>(s_smp + blk * COEF_STRIDE + row * 8);
         }
     }
 
@@ -348,7 +383,7 @@ __global__ __launch_bounds__(TPB, MJ_IDCT_WAVES) void mj_k_idct_colour(MjDeviceB
             }
             const uint32_t x = qx * 4, gy = py0 + y, gx = px0 + x;
             if (gy >= im.Y || gx >= im.X) continue;
-            const uint32_t v = *reinterpret_cast<const uint32_t *>(s_plane + y * pw0 + x);
+            const uint32_t v = *reinterpret_cast<const uint32_t *>(s_smp + smp(sb0, hs0, x, y));
             const uint32_t a = v & 0xFF, bb = (v >> 8) & 0xFF, cc = (v >> 16) & 0xFF, d = v >> 24;
             uint8_t *o = rgb + (uint64_t) gy * im.pitch + 3 * gx;
             if (gx + 4 <= im.X) {
@@ -367,12 +402,11 @@ __global__ __launch_bounds__(TPB, MJ_IDCT_WAVES) void mj_k_idct_colour(MjDeviceB
     }
     {
         const uint32_t ch = im.hmax / im.comp[1].hsf, cv = im.vmax / im.comp[1].vsf;
-        const bool same = im.comp[1].hsf == im.comp[2].hsf && im.comp[1].vsf == im.comp[2].vsf &&
+        const bool same = im.comp[1].hsf == 1 && im.comp[1].vsf == 1 && im.comp[2].hsf == 1 && im.comp[2].vsf == 1 &&
                           im.comp[0].hsf == im.hmax && im.comp[0].vsf == im.vmax;
         if (same && ch != 3 && cv <= 2) {
-            const uint32_t pwc = pw1;
 #define MJ_FAST(SH, SV)                                                                                          \
-    colour_fast<SH, SV>(s_plane, s_tcb, s_tcr, po1, po2, pw0, pwc, tile_w, tile_h, px0, py0, im.X, im.Y, im.pitch, rgb)
+    colour_fast<SH, SV>(s_smp, s_tcb, s_tcr, bpm, sb0, sb1, sb2, tile_w, tile_h, px0, py0, im.X, im.Y, im.pitch, rgb)
             if (cv == 1) {
                 if (ch == 1) MJ_FAST(0, 0);
                 else if (ch == 2) MJ_FAST(1, 0);
@@ -388,13 +422,9 @@ __global__ __launch_bounds__(TPB, MJ_IDCT_WAVES) void mj_k_idct_colour(MjDeviceB
     }
     /* Source sample of output (i, j) in component c is (uint32)(ratio * i) with
      * ratio = (float) sf_c / max_sf (colour_conversion.c:44-45, :62-69).  Sampling
-     * factors divide the maximum here, so that is i / (max_sf / sf_c): a shift when
-     * the quotient is 1, 2 or 4, a division by 3 otherwise. */
+     * factors divide the maximum here, so that is i / (max_sf / sf_c). */
     const uint32_t qh0 = im.hmax / im.comp[0].hsf, qh1 = im.hmax / im.comp[1].hsf, qh2 = im.hmax / im.comp[2].hsf;
     const uint32_t qv0 = im.vmax / im.comp[0].vsf, qv1 = im.vmax / im.comp[1].vsf, qv2 = im.vmax / im.comp[2].vsf;
-    const bool pow2 = qh0 != 3 && qh1 != 3 && qh2 != 3 && qv0 != 3 && qv1 != 3 && qv2 != 3;
-    const uint32_t sh0 = qh0 >> 1, sh1 = qh1 >> 1, sh2 = qh2 >> 1;   /* 1,2,4 -> 0,1,2 */
-    const uint32_t sv0 = qv0 >> 1, sv1 = qv1 >> 1, sv2 = qv2 >> 1;
     for (; y < tile_h; y += dy, qx += dq) {
         if (qx >= quads) {
             qx -= quads;
@@ -403,26 +433,12 @@ __global__ __launch_bounds__(TPB, MJ_IDCT_WAVES) void mj_k_idct_colour(MjDeviceB
         }
         const uint32_t x = qx * 4, gy = py0 + y, gx = px0 + x;
         if (gy >= im.Y || gx >= im.X) continue;
-        const uint8_t *r0, *r1, *r2;
         uint32_t px[4];
-        if (pow2) {
-            r0 = s_plane + po0 + (y >> sv0) * pw0;
-            r1 = s_plane + po1 + (y >> sv1) * pw1;
-            r2 = s_plane + po2 + (y >> sv2) * pw2;
 #pragma unroll
-            for (uint32_t k = 0; k < 4; k++) {
-                const uint32_t xx = x + k;
-                px[k] = ycc_to_rgb24(r0[xx >> sh0], s_tcb[r1[xx >> sh1]], s_tcr[r2[xx >> sh2]]);
-            }
-        } else {
-            r0 = s_plane + po0 + (y / qv0) * pw0;
-            r1 = s_plane + po1 + (y / qv1) * pw1;
-            r2 = s_plane + po2 + (y / qv2) * pw2;
-#pragma unroll
-            for (uint32_t k = 0; k < 4; k++) {
-                const uint32_t xx = x + k;
-                px[k] = ycc_to_rgb24(r0[xx / qh0], s_tcb[r1[xx / qh1]], s_tcr[r2[xx / qh2]]);
-            }
+        for (uint32_t k = 0; k < 4; k++) {
+            const uint32_t xx = x + k;
+            px[k] = ycc_to_rgb24(s_smp[smp(sb0, hs0, xx / qh0, y / qv0)], s_tcb[s_smp[smp(sb1, hs1, xx / qh1, y / qv1)]],
+                                 s_tcr[s_smp[smp(sb2, hs2, xx / qh2, y / qv2)]]);
         }
         store_quad(rgb + (uint64_t) gy * im.pitch + 3 * gx, px, gx, im.X);
     }
