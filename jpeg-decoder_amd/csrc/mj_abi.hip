@@ -318,7 +318,11 @@ static int batch_build(mj_ctx *ctx, std::vector<MjPrepared> &prep, uint32_t flag
     d.want_planes = (flags & MJ_WANT_PLANES) ? 1u : 0u;
     d.dbg = (flags >> 16) & 0xFFFFu;
     d.max_ntab = 1;
-    for (const MjHuffSet &hs : b->sets) d.max_ntab = hs.ntab > d.max_ntab ? hs.ntab : d.max_ntab;
+    d.max_nac = 1;
+    for (const MjHuffSet &hs : b->sets) {
+        d.max_ntab = hs.ntab > d.max_ntab ? hs.ntab : d.max_ntab;
+        d.max_nac = hs.nac > d.max_nac ? hs.nac : d.max_nac;
+    }
     b->coef_bytes = coef_blocks * 128;
     b->rgb_bytes = rgb_total;
     b->plane_bytes = plane_total;

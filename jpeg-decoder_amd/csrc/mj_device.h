@@ -74,12 +74,17 @@ typedef struct {
     uint16_t pair[MJ_LUT_SIZE];
 } MjHuffPair;
 
+/* The tables one scan uses.  AC tables come first (indices 0 .. nac-1), DC tables after
+ * them, so the per-AC-table side tables below are dense. */
 typedef struct {
     uint32_t ntab;
-    uint32_t pad_[3];
+    uint32_t nac;
+    uint32_t pad_[2];
     MjHuffDev tab[MJ_MAX_TABS];
     MjHuffWalk walk[MJ_MAX_TABS];
-    MjHuffPair pair[MJ_MAX_TABS];   /* all zero for DC tables */
+    MjHuffPair pair[MJ_MAX_TABS / 2];   /* counting passes: runs of whole AC symbols */
+    MjHuffPair next[MJ_MAX_TABS / 2];   /* writing pass: lookup entry of the AC symbol that follows the one the index
+                                           starts with, when its code lies inside the index bits too; 0 = none */
 } MjHuffSet;
 
 typedef struct {

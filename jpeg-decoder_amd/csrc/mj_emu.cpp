@@ -122,6 +122,8 @@ int64_t mj_emu_decode_coefs(const uint8_t *file, size_t len, int16_t *coefs, int
     cx.pairs = (const unsigned char *) set->pair;
     cx.coefs = coefs;
     cx.wi_mask = 0xFFFFFFFFu;
+    MjScanCtx wcx = cx;   /* the writing pass looks up second symbols, not runs */
+    wcx.pairs = (const unsigned char *) set->next;
 
     int64_t st_subs = 0, st_rounds = 0, st_maxr = 0, st_seqs = 0, st_multi = 0, st_fix = 0, st_tasks = 0;
     // MJ_EMU_HIST=1: print, per round, how many decoders are still out of step
@@ -229,19 +231,19 @@ int64_t mj_emu_decode_coefs(const uint8_t *file, size_t len, int16_t *coefs, int
             const uint32_t jl = (j + G < nsub) ? j + G - 1 : nsub - 1;   // the lane's last subsequence
             uint32_t p = j ? rec[j - 1].p : b0, k = j ? rec[j - 1].k : 0, c = j ? rec[j - 1].c : 0;
             uint32_t blk = blk0;
-            int32_t d[4] = {pred[0], pred[1], pred[2], pred[3]};
+            MjAccReg d = {pred[0], pred[1], pred[2], pred[3]};
             bool skip = (k != 0);
             int16_t buf[64];
             memset(buf, 0, sizeof buf);
             const uint32_t end = sub_end(jl);
             if (mj_write_live(p, k, skip, end, b1)) {
                 MjLane L;
-                mj_lane_init(cx, L, p, k, c);
+                mj_lane_init(wcx, L, p, k, c);
                 while (mj_write_live(L.p, L.k, skip, end, b1)) {
-                    mj_checkpoint(cx, L);
+                    mj_checkpoint(wcx, L);
                     bool fin = false;
                     uint32_t fin_blk = 0;
-                    mj_write_step(cx, L, skip, blk, blk_end, d, 1, buf, fin, fin_blk);
+                    mj_write_step(wcx, L, skip, blk, blk_end, d, buf, fin, fin_blk);
                     if (fin) {
                         memcpy(coefs + (size_t) fin_blk * 64, buf, sizeof buf);
                         memset(buf, 0, sizeof buf);

@@ -23,8 +23,10 @@
 
 #if defined(__HIPCC__)
 #define MJ_HD __host__ __device__ __forceinline__
+#define MJ_HDM __host__ __device__ __forceinline__
 #else
 #define MJ_HD static inline
+#define MJ_HDM inline
 #endif
 
 /* Per block slot of the MCU, eight bits: bits 0-1 component, bits 2-4 index of its DC
@@ -40,7 +42,8 @@ struct MjScanCtx {
     const uint32_t *stream;      /* the image's compacted stream, 32-bit words in file byte order; 16-byte aligned on the device */
     const unsigned char *tabs;   /* the image's MjHuffDev array (LDS on the device) */
     const MjHuffWalk *walk;      /* the matching canonical ranges (HBM on the device) */
-    const unsigned char *pairs;  /* the matching MjHuffPair array (LDS on the device); only the counting passes read it */
+    const unsigned char *pairs;  /* MjHuffPair per AC table (LDS on the device): the runs for the counting passes, or the
+                                    second-symbol entries for the writing pass */
     uint32_t slotw0, slotw1, slotw2; /* mj_slot_desc() of slot i in byte i & 3 of word i >> 2 (separate members: never indexed) */
     int16_t *coefs;              /* block 0 of the image; 64 int16 per block, zigzag order */
     uint32_t bpm;                /* blocks per MCU */
@@ -220,29 +223,46 @@ MJ_HD void mj_refill(MjLane &L) {
 }
 
 /* Per-component DC accumulators (decode.c:682-690; the int16 wrap is applied when a
- * value is stored): lane-private words acc[comp * stride], in LDS on the device so
- * that the component index costs one address computation instead of a select per
- * component.  RETURN: give back the updated accumulator. */
-template <bool RETURN>
-MJ_HD int32_t mj_dc_add(int32_t *acc, uint32_t stride, uint32_t comp, int32_t v) {
+ * value is stored).  Two homes: lane-private words in memory, acc[comp * stride] (LDS on
+ * the device, where the component index costs one address computation and the addition
+ * one LDS operation that nobody waits for) for the counting passes; four registers for
+ * the writing pass, which needs the sum back at once. */
+struct MjAccMem {
+    int32_t *p;
+    uint32_t stride;
+    MJ_HDM int32_t add(uint32_t comp, int32_t v) const {
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (RETURN) {
-        return __hip_atomic_fetch_add(acc + comp * stride, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) + v;
-    }
-    (void) __hip_atomic_fetch_add(acc + comp * stride, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-    return 0;
+        (void) __hip_atomic_fetch_add(p + comp * stride, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        return 0;
 #else
-    acc[comp * stride] += v;
-    return acc[comp * stride];
+        p[comp * stride] += v;
+        return p[comp * stride];
 #endif
-}
+    }
+};
+
+struct MjAccReg {
+    int32_t d0, d1, d2, d3;
+    MJ_HDM int32_t add(uint32_t comp, int32_t v) {
+        const int32_t lo = (comp & 1u) ? d1 : d0, hi = (comp & 1u) ? d3 : d2;
+        const int32_t sum = ((comp & 2u) ? hi : lo) + v;
+        d0 = (comp == 0) ? sum : d0;
+        d1 = (comp == 1) ? sum : d1;
+        d2 = (comp == 2) ? sum : d2;
+        d3 = (comp == 3) ? sum : d3;
+        return sum;
+    }
+};
 
 /* What one symbol did. */
 struct MjSym {
     int32_t val;      /* WRITE only: the coefficient value (for DC: the predictor after the addition) */
     uint32_t kpos;    /* zigzag position the value belongs to (0 for DC) */
     bool store;       /* WRITE only: val is a coefficient to store (DC always; AC when size != 0 and in range) */
-    bool done;        /* the block ended with this symbol */
+    int32_t val2;     /* WRITE only: a second AC symbol taken in the same step */
+    uint32_t kpos2;
+    bool store2;
+    bool done;        /* the block ended with this step */
 };
 
 /* A first-level entry that is not a code: second-level table or canonical walk. */
@@ -272,15 +292,12 @@ MJ_HD uint32_t mj_long_code(const MjScanCtx &cx, const MjLane &L, uint32_t e) {
  * the blocks that end.  WRITE: also produce the coefficient to store (the writing
  * pass needs it, the synchronisation passes only need bit counts and DC sums).
  */
-template <bool WRITE>
-MJ_HD MjSym mj_step(const MjScanCtx &cx, MjLane &L, int32_t *acc, uint32_t stride, uint32_t &nb, uint32_t end) {
+template <bool WRITE, class ACC>
+MJ_HD MjSym mj_step(const MjScanCtx &cx, MjLane &L, ACC &acc, uint32_t &nb, uint32_t end) {
     MjSym s;
     const uint32_t idx2 = (L.hi >> (32 - MJ_LUT_BITS)) << 1;
     uint32_t e = *reinterpret_cast<const uint16_t *>(cx.tabs + L.tcur + idx2);
-    uint32_t d = 0;
-    if (!WRITE) {
-        d = *reinterpret_cast<const uint16_t *>(cx.pairs + L.pcur + idx2);
-    }
+    const uint32_t d = *reinterpret_cast<const uint16_t *>(cx.pairs + L.pcur + idx2);
     if (MJ_E_LEN(e) == 0) {
         e = mj_long_code(cx, L, e);
     }
@@ -288,6 +305,10 @@ MJ_HD MjSym mj_step(const MjScanCtx &cx, MjLane &L, int32_t *acc, uint32_t strid
     uint32_t used = MJ_E_LEN(e) + size;            /* 1..31 */
     uint32_t step = e & 127u;                      /* run + 1; 64 on end of block; ZRL nets 16 */
     const bool dc = (L.k == 0);
+    s.val = 0;
+    s.val2 = 0;
+    s.kpos2 = 0;
+    s.store2 = false;
     if (!WRITE) {
         /* a run of whole AC symbols in one go, when the block lasts up to the run's last
          * symbol and the run ends inside the span: exactly what that many single steps
@@ -297,25 +318,39 @@ MJ_HD MjSym mj_step(const MjScanCtx &cx, MjLane &L, int32_t *acc, uint32_t strid
         used = run ? run_used : used;
         step = run ? run_before + (d & 127u) : step;
     }
-    const uint32_t back = 32u - used;
-    s.val = 0;
     if (WRITE || dc) {
         /* the `size` bits after the code, then EXTEND (decode.c:684-686, :716-718):
          * a leading 1 means the value as read, a leading 0 means value - 2^size + 1 */
-        const uint32_t v = mj_bfe(L.hi, back, size);
+        const uint32_t v = mj_bfe(L.hi, 32u - used, size);
         const uint32_t full = 1u << size;
         s.val = (v < (full >> 1)) ? (int32_t) (v + 1u - full) : (int32_t) v;
         if (dc) {
-            s.val = mj_dc_add<WRITE>(acc, stride, L.slot & 3u, s.val);
+            s.val = acc.add(L.slot & 3u, s.val);
             L.tcur = mj_slot_tac(L.slot);
         }
     }
-    L.hi = mj_align(L.hi, L.lo, back);
+    const uint32_t k1 = L.k + step;
+    s.kpos = dc ? 0u : k1 - 1u;
+    s.store = dc || (size != 0 && k1 <= 64u);
+    L.k = k1;
+    if (WRITE) {
+        /* the next AC symbol as well, when its code lay inside the lookup index and the
+         * block goes on: two single steps in one */
+        if ((d != 0) && !dc && (k1 < 64u)) {
+            const uint32_t size2 = mj_bfe(d, 7, 4);
+            used += MJ_E_LEN(d) + size2;           /* at most 10 + 15 */
+            const uint32_t v = mj_bfe(L.hi, 32u - used, size2);
+            const uint32_t full = 1u << size2;
+            s.val2 = (v < (full >> 1)) ? (int32_t) (v + 1u - full) : (int32_t) v;
+            const uint32_t k2 = k1 + (d & 127u);
+            s.kpos2 = k2 - 1u;
+            s.store2 = (size2 != 0 && k2 <= 64u);
+            L.k = k2;
+        }
+    }
+    L.hi = mj_align(L.hi, L.lo, 32u - used);
     L.lo <<= used;
     L.p += used;
-    L.k += step;
-    s.kpos = dc ? 0u : L.k - 1u;
-    s.store = dc || (size != 0 && L.k <= 64u);
     s.done = (L.k >= 64u);
     if (s.done) {
         L.k = 0;
@@ -335,12 +370,13 @@ MJ_HD MjSym mj_step(const MjScanCtx &cx, MjLane &L, int32_t *acc, uint32_t strid
  */
 MJ_HD void mj_run_span(const MjScanCtx &cx, MjLane &L, uint32_t end, uint32_t &nb, int32_t *acc, uint32_t stride) {
     uint32_t it = 0;
+    MjAccMem am = {acc, stride};
     while (L.p < end) {
         if ((it++ % MJ_CHECK_EVERY) == 0) {
             mj_checkpoint(cx, L);
         }
         mj_refill(L);
-        (void) mj_step<false>(cx, L, acc, stride, nb, end);
+        (void) mj_step<false>(cx, L, am, nb, end);
     }
 }
 
@@ -367,17 +403,21 @@ MJ_HD void mj_decode_span(const MjScanCtx &cx, uint32_t &p, uint32_t &k, uint32_
  * entry state is in the middle of a block (k != 0) runs in `skip` mode until that
  * block ends -- the previous lane finishes it by decoding past its own subsequence
  * end (see mj_write_live) -- so every block is assembled by exactly one lane and
- * leaves the chip as one full 128-byte line.  acc holds the DC predictors.  The caller
+ * leaves the chip as one full 128-byte line.  acc holds the DC predictors; cx.pairs
+ * must point at the second-symbol tables (MjHuffSet.next).  The caller
  * runs mj_checkpoint at least every MJ_CHECK_EVERY steps.
  */
-MJ_HD void mj_write_step(const MjScanCtx &cx, MjLane &L, bool &skip, uint32_t &blk, uint32_t blk_end, int32_t *acc,
-                         uint32_t stride, int16_t *blkbuf, bool &fin, uint32_t &fin_blk) {
+MJ_HD void mj_write_step(const MjScanCtx &cx, MjLane &L, bool &skip, uint32_t &blk, uint32_t blk_end, MjAccReg &acc,
+                         int16_t *blkbuf, bool &fin, uint32_t &fin_blk) {
     mj_refill(L);
     uint32_t ended = 0;
-    const MjSym s = mj_step<true>(cx, L, acc, stride, ended, 0);
+    const MjSym s = mj_step<true>(cx, L, acc, ended, 0);
     const bool mine = !skip && blk < blk_end;
     if (s.store && mine) {
         blkbuf[s.kpos] = (int16_t) s.val;
+    }
+    if (s.store2 && mine) {
+        blkbuf[s.kpos2] = (int16_t) s.val2;
     }
     fin = false;
     if (s.done) {

@@ -85,20 +85,19 @@ __device__ __forceinline__ unsigned char *lds_after_dc(const MjDeviceBatch &b, u
     return reinterpret_cast<unsigned char *>(lds_dc(b)) + waves * DC_WAVE_BYTES;
 }
 
-/* cooperative copy of the image's Huffman tables into LDS -- and, for the counting
- * kernels, of the symbol-run tables into `pairs` (the caller synchronises) */
-__device__ __forceinline__ void load_tables(const MjDeviceBatch &b, const MjImageDev &im, unsigned char *pairs) {
+/* cooperative copy of the image's Huffman tables into LDS, and of one side table per AC
+ * table into `pairs`: the symbol runs for the counting kernels, the second-symbol
+ * entries for the writing kernel (the caller synchronises) */
+__device__ __forceinline__ void load_tables(const MjDeviceBatch &b, const MjImageDev &im, unsigned char *pairs, bool runs) {
     const MjHuffSet &set = b.sets[im.huff_set];
     const uint32_t n = set.ntab * (uint32_t) (sizeof(MjHuffDev) / 16);
     const uint4 *src = reinterpret_cast<const uint4 *>(set.tab);
     uint4 *dst = reinterpret_cast<uint4 *>(s_dyn);
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
-    if (pairs) {
-        const uint32_t np = set.ntab * (uint32_t) (sizeof(MjHuffPair) / 16);
-        const uint4 *psrc = reinterpret_cast<const uint4 *>(set.pair);
-        uint4 *pdst = reinterpret_cast<uint4 *>(pairs);
-        for (uint32_t i = threadIdx.x; i < np; i += blockDim.x) pdst[i] = psrc[i];
-    }
+    const uint32_t np = set.nac * (uint32_t) (sizeof(MjHuffPair) / 16);
+    const uint4 *psrc = reinterpret_cast<const uint4 *>(runs ? set.pair : set.next);
+    uint4 *pdst = reinterpret_cast<uint4 *>(pairs);
+    for (uint32_t i = threadIdx.x; i < np; i += blockDim.x) pdst[i] = psrc[i];
 }
 
 __device__ __forceinline__ MjScanCtx make_ctx(const MjDeviceBatch &b, const MjImageDev &im, const unsigned char *pairs) {
@@ -225,7 +224,7 @@ __global__ __launch_bounds__(SYNC_TPB) void mj_k_entropy_sync(MjDeviceBatch b) {
     unsigned char *s_pairs = reinterpret_cast<unsigned char *>(s_queue + 2 * SYNC_TPB);
 
     const uint32_t S = im.sub_bits, G = im.lane_subs, SQ = MJ_SEQ_LANES * G;
-    load_tables(b, im, s_pairs);
+    load_tables(b, im, s_pairs, true);
     if (threadIdx.x < SYNC_WAVES) {
         SeqGeo sg = {0, 0, 0, 0, 0, 0, {0, 0}};
         const uint32_t seq = seq0 + threadIdx.x;
@@ -333,7 +332,7 @@ __global__ __launch_bounds__(FIX_TPB) void mj_k_entropy_fix(MjDeviceBatch b) {
     const Geo g = interval_geo(b.ivl_start + im.ivl_off, iv, S, SQ);
     const uint32_t seq_first = im.seq_off + b.ivl_seq[im.ivl_off + iv]; /* global slot of the interval's first sequence */
     unsigned char *s_pairs = lds_after_dc(b, FIX_TPB / 64);
-    load_tables(b, im, s_pairs);
+    load_tables(b, im, s_pairs, true);
     __syncthreads();
     const MjScanCtx cx = make_ctx(b, im, s_pairs);
     int32_t *fix_acc = lds_dc(b) + (threadIdx.x >> 6) * 64 * MJ_MAX_COMP + (threadIdx.x & 63);
@@ -455,8 +454,8 @@ __global__ __launch_bounds__(FIX_TPB) void mj_k_entropy_fix(MjDeviceBatch b) {
 constexpr int BLK_STRIDE = 128;   /* bytes per lane block buffer (unpadded: LDS capacity decides the occupancy here) */
 
 __global__ __launch_bounds__(TPB) void mj_k_entropy_write(MjDeviceBatch b) {
-    /* dynamic LDS: [tables][DC accumulators][block buffers: TPB x 128 B][flush lists: TPB x (4 + 4) B] */
-    unsigned char *s_blk = lds_after_dc(b, WAVES);
+    /* dynamic LDS: [tables][block buffers: TPB x 128 B][flush lists: TPB x (4 + 4) B][second-symbol tables] */
+    unsigned char *s_blk = lds_after_dc(b, 0);
     uint32_t *s_list_blk = reinterpret_cast<uint32_t *>(s_blk + TPB * BLK_STRIDE);
     uint32_t *s_list_lane = s_list_blk + TPB;
 
@@ -467,7 +466,8 @@ __global__ __launch_bounds__(TPB) void mj_k_entropy_write(MjDeviceBatch b) {
     const uint32_t n_seq = b.dyn[ii].n_seq;
     const uint32_t seq0 = (grp - im.wg_first) * MJ_WG_SEQS + part * WAVES;
     if (seq0 >= n_seq) return;
-    load_tables(b, im, nullptr);
+    unsigned char *s_next = reinterpret_cast<unsigned char *>(s_list_lane + TPB);
+    load_tables(b, im, s_next, false);
     {   /* zero the block buffers */
         uint4 *z = reinterpret_cast<uint4 *>(s_blk);
         for (uint32_t i = threadIdx.x; i < TPB * BLK_STRIDE / 16; i += TPB) z[i] = make_uint4(0, 0, 0, 0);
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(TPB) void mj_k_entropy_write(MjDeviceBatch b) {
     const uint32_t first = b.seq_sub[im.seq_off + seq];
     const Geo g = interval_geo(b.ivl_start + im.ivl_off, iv, S, SQ);
     const uint32_t n = min(g.nsub - first, SQ);
-    const MjScanCtx cx = make_ctx(b, im, nullptr);
+    const MjScanCtx cx = make_ctx(b, im, s_next);
     /* the lane's subsequences: u0 .. u0 + cnt - 1 of the sequence */
     const uint32_t u0 = lane * G;
     const bool valid = u0 < n;
@@ -527,11 +527,7 @@ __global__ __launch_bounds__(TPB) void mj_k_entropy_write(MjDeviceBatch b) {
 
     uint32_t k = kc & 0xFFu, c = kc >> 8;
     uint32_t blk = se.blk + nb;
-    int32_t *acc = lds_dc(b) + wave * 64 * MJ_MAX_COMP + lane;
-    acc[0] = d0 + se.pred[0];
-    acc[64] = d1 + se.pred[1];
-    acc[128] = d2 + se.pred[2];
-    acc[192] = d3 + se.pred[3];
+    MjAccReg acc = {d0 + se.pred[0], d1 + se.pred[1], d2 + se.pred[2], d3 + se.pred[3]};
     bool skip = (k != 0);
     const uint32_t end = sub_end(g.b0, g.b1, g.nsub, first + u0 + (cnt ? cnt - 1 : 0), S);
     int16_t *blkbuf = reinterpret_cast<int16_t *>(s_blk + (wave * 64 + lane) * BLK_STRIDE);
@@ -548,7 +544,7 @@ __global__ __launch_bounds__(TPB) void mj_k_entropy_write(MjDeviceBatch b) {
         uint32_t fin_blk = 0;
         if (live && (it % MJ_CHECK_EVERY) == 0) mj_checkpoint(cx, L);
         if (live) {
-            mj_write_step(cx, L, skip, blk, blk_end, acc, 64, blkbuf, fin, fin_blk);
+            mj_write_step(cx, L, skip, blk, blk_end, acc, blkbuf, fin, fin_blk);
             live = mj_write_live(L.p, L.k, skip, end, g.b1);
         }
         const unsigned long long mask = __ballot(fin);
@@ -582,9 +578,10 @@ __global__ __launch_bounds__(TPB) void mj_k_entropy_write(MjDeviceBatch b) {
 __global__ __launch_bounds__(TPB) void mj_k_entropy_serial(MjDeviceBatch b) {
     const uint32_t ii = blockIdx.x;
     const MjImageDev &im = b.img[ii];
-    load_tables(b, im, nullptr);
+    unsigned char *s_next = lds_after_dc(b, WAVES);
+    load_tables(b, im, s_next, false);
     __syncthreads();
-    const MjScanCtx cx = make_ctx(b, im, nullptr);
+    const MjScanCtx cx = make_ctx(b, im, s_next);
     const uint32_t *ivl = b.ivl_start + im.ivl_off;
     const uint32_t n_blocks = im.n_mcu * im.bpm;
     for (uint32_t iv = threadIdx.x; iv < im.n_ivl; iv += TPB) {
@@ -594,14 +591,14 @@ __global__ __launch_bounds__(TPB) void mj_k_entropy_serial(MjDeviceBatch b) {
         if (p0 >= end) continue;
         MjLane L;
         mj_lane_init(cx, L, p0, 0, 0);
-        int32_t *acc = lds_dc(b) + (threadIdx.x >> 6) * 64 * MJ_MAX_COMP + (threadIdx.x & 63);
-        acc[0] = acc[64] = acc[128] = acc[192] = 0;
+        MjAccReg acc = {0, 0, 0, 0};
         while (L.p < end && blk < blk_end) {
             mj_checkpoint(cx, L);
             mj_refill(L);
             const uint32_t at = blk;
-            const MjSym s = mj_step<true>(cx, L, acc, 64, blk, 0);
+            const MjSym s = mj_step<true>(cx, L, acc, blk, 0);
             if (s.store) cx.coefs[(uint64_t) at * 64 + s.kpos] = (int16_t) s.val;
+            if (s.store2) cx.coefs[(uint64_t) at * 64 + s.kpos2] = (int16_t) s.val2;
         }
     }
 }
@@ -616,7 +613,7 @@ hipError_t mj_launch_entropy(const MjDeviceBatch &b, hipStream_t s) {
     if (b.n_entropy_wg == 0) return hipSuccess;
     static const size_t pad = getenv("MJ_TUNE_LDS_PAD") ? (size_t) atol(getenv("MJ_TUNE_LDS_PAD")) : 0;   /* occupancy experiments */
     const size_t lds = table_lds(b, SYNC_WAVES) + SYNC_WAVES * sizeof(SeqGeo) + 4 * sizeof(uint32_t) + 2 * SYNC_TPB * sizeof(uint2) +
-                       (size_t) b.max_ntab * sizeof(MjHuffPair) + pad;
+                       (size_t) b.max_nac * sizeof(MjHuffPair) + pad;
     hipLaunchKernelGGL(mj_k_entropy_sync, dim3(b.n_entropy_wg), dim3(SYNC_TPB), lds, s, b);
     return hipGetLastError();
 }
@@ -624,19 +621,19 @@ hipError_t mj_launch_entropy(const MjDeviceBatch &b, hipStream_t s) {
 hipError_t mj_launch_entropy_fix(const MjDeviceBatch &b, hipStream_t s) {
     if (b.n_multi_cap == 0 || b.n_entropy_wg == 0) return hipSuccess;
     hipLaunchKernelGGL(mj_k_entropy_fix, dim3(b.n_multi_cap), dim3(FIX_TPB),
-                       table_lds(b, FIX_TPB / 64) + (size_t) b.max_ntab * sizeof(MjHuffPair), s, b);
+                       table_lds(b, FIX_TPB / 64) + (size_t) b.max_nac * sizeof(MjHuffPair), s, b);
     return hipGetLastError();
 }
 
 hipError_t mj_launch_entropy_write(const MjDeviceBatch &b, hipStream_t s) {
     if (b.n_entropy_wg == 0) return hipSuccess;
-    const size_t lds = table_lds(b, WAVES) + (size_t) TPB * BLK_STRIDE + (size_t) TPB * 8;
+    const size_t lds = table_lds(b, 0) + (size_t) TPB * BLK_STRIDE + (size_t) TPB * 8 + (size_t) b.max_nac * sizeof(MjHuffPair);
     hipLaunchKernelGGL(mj_k_entropy_write, dim3(b.n_entropy_wg * (MJ_WG_SEQS / WAVES)), dim3(TPB), lds, s, b);
     return hipGetLastError();
 }
 
 hipError_t mj_launch_entropy_serial(const MjDeviceBatch &b, hipStream_t s) {
     if (b.n_img == 0) return hipSuccess;
-    hipLaunchKernelGGL(mj_k_entropy_serial, dim3(b.n_img), dim3(TPB), table_lds(b, WAVES), s, b);
+    hipLaunchKernelGGL(mj_k_entropy_serial, dim3(b.n_img), dim3(TPB), table_lds(b, WAVES) + (size_t) b.max_nac * sizeof(MjHuffPair), s, b);
     return hipGetLastError();
 }

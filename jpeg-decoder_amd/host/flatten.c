@@ -121,10 +121,11 @@ void mj_parsed_free(MjParsed *p) {
     memset(p, 0, sizeof *p);
 }
 
-void mj_flatten_huff(const HuffTable *ht, int is_ac, MjHuffDev *out, MjHuffWalk *walk, MjHuffPair *pair) {
+void mj_flatten_huff(const HuffTable *ht, int is_ac, MjHuffDev *out, MjHuffWalk *walk, MjHuffPair *pair, MjHuffPair *next) {
     memset(out, 0, sizeof *out);
     memset(walk, 0, sizeof *walk);
-    memset(pair, 0, sizeof *pair);
+    if (pair) memset(pair, 0, sizeof *pair);
+    if (next) memset(next, 0, sizeof *next);
     walk->maxcode[0] = -1;
     int nvals = 0;
     uint32_t nsub = 0;
@@ -185,7 +186,7 @@ void mj_flatten_huff(const HuffTable *ht, int is_ac, MjHuffDev *out, MjHuffWalk 
             if (out->sub[t][j] == 0) out->sub[t][j] = none;
         }
     }
-    if (!is_ac) {
+    if (!is_ac || !pair || !next) {
         return;
     }
     /* runs of whole symbols inside one first-level index (see MjHuffPair) */
@@ -212,6 +213,15 @@ void mj_flatten_huff(const HuffTable *ht, int is_ac, MjHuffDev *out, MjHuffWalk 
         }
         if (n >= 2 && used <= 31) {
             pair->pair[idx] = (uint16_t) ((used << 11) | (before << 7) | last);
+        }
+        /* the symbol after the first one, for the pass that needs every value */
+        const uint32_t e1 = out->lut[idx];
+        const uint32_t used1 = MJ_E_LEN(e1) + ((e1 >> 7) & 15u);
+        if (MJ_E_LEN(e1) != 0 && (e1 & 127u) != 64u && used1 < MJ_LUT_BITS) {
+            const uint32_t e2 = out->lut[(idx << used1) & (MJ_LUT_SIZE - 1)];
+            if (MJ_E_LEN(e2) != 0 && MJ_E_LEN(e2) <= MJ_LUT_BITS - used1) {
+                next->pair[idx] = (uint16_t) e2;
+            }
         }
     }
 }
@@ -308,9 +318,35 @@ int mj_flatten_image(const MjParsed *p, size_t file_len, MjImageDev *img, MjHuff
     }
     img->n_mcu = img->mcus_x * img->mcus_y;
 
-    /* block slots of one MCU in scan order, and the Huffman tables they use */
+    /* block slots of one MCU in scan order, and the Huffman tables they use: AC tables
+     * take the first indices, DC tables follow */
     uint32_t bpm = 0;
     int dc_slot[4] = {-1, -1, -1, -1}, ac_slot[4] = {-1, -1, -1, -1};
+    for (int s = 0; s < sh->nics; s++) {
+        int td = sh->ics[s].dc, ta = sh->ics[s].ac;
+        if (td > 3 || ta > 3) {
+            return fail(why, "bad Huffman table selector");
+        }
+        if (ac_slot[ta] < 0) {
+            ac_slot[ta] = (int) set->nac++;
+        }
+    }
+    set->ntab = set->nac;
+    for (int s = 0; s < sh->nics; s++) {
+        int td = sh->ics[s].dc;
+        if (dc_slot[td] < 0) {
+            dc_slot[td] = (int) set->ntab++;
+        }
+    }
+    for (int t = 0; t < 4; t++) {
+        if (ac_slot[t] >= 0) {
+            mj_flatten_huff(&p->hts.DCAC[TC_AC][t], 1, &set->tab[ac_slot[t]], &set->walk[ac_slot[t]], &set->pair[ac_slot[t]],
+                            &set->next[ac_slot[t]]);
+        }
+        if (dc_slot[t] >= 0) {
+            mj_flatten_huff(&p->hts.DCAC[TC_DC][t], 0, &set->tab[dc_slot[t]], &set->walk[dc_slot[t]], NULL, NULL);
+        }
+    }
     for (int s = 0; s < sh->nics; s++) {
         int ci = -1;
         for (int j = 0; j < fh->ncs; j++) {
@@ -323,19 +359,6 @@ int mj_flatten_image(const MjParsed *p, size_t file_len, MjImageDev *img, MjHuff
             return fail(why, "scan names an unknown component");
         }
         int td = sh->ics[s].dc, ta = sh->ics[s].ac;
-        if (td > 3 || ta > 3) {
-            return fail(why, "bad Huffman table selector");
-        }
-        if (dc_slot[td] < 0) {
-            dc_slot[td] = (int) set->ntab;
-            mj_flatten_huff(&p->hts.DCAC[TC_DC][td], 0, &set->tab[set->ntab], &set->walk[set->ntab], &set->pair[set->ntab]);
-            set->ntab++;
-        }
-        if (ac_slot[ta] < 0) {
-            ac_slot[ta] = (int) set->ntab;
-            mj_flatten_huff(&p->hts.DCAC[TC_AC][ta], 1, &set->tab[set->ntab], &set->walk[set->ntab], &set->pair[set->ntab]);
-            set->ntab++;
-        }
         const Component *c = &fh->cs[ci];
         for (int v = 0; v < c->vsf; v++) {
             for (int h = 0; h < c->hsf; h++) {
