@@ -114,17 +114,33 @@ __device__ __forceinline__ uint32_t store8(float v) {
     return (v == 256.0f) ? 0u : r;
 }
 
-/* colour_conversion.c:71-74.  The products with the chroma samples come from
- * per-workgroup LDS tables indexed by the sample value:
- *   cr -> (1.402 * (cr - 128), 0.71414 * (cr - 128)),  cb -> (0.34414 * (cb - 128), 1.772 * (cb - 128))
- * computed once per value in double exactly as the expression does; the adds keep
- * the source's left-to-right order. */
-__device__ __forceinline__ uint32_t ycc_to_rgb24(uint32_t Y, const double2 tcb, const double2 tcr) {
+/* colour_conversion.c:71-74, per chroma sample value, from per-workgroup LDS tables:
+ *   cb -> g = 0.34414 * (cb - 128) in double, o = floor(1.772 * (cb - 128))
+ *   cr -> g = 0.71414 * (cr - 128) in double, o = floor(1.402 * (cr - 128))
+ * G keeps the reference's arithmetic: (y - g_cb) - g_cr in double, left to right,
+ * rounded to float, truncated.  R = y + 1.402 (cr - 128) and B = y + 1.772 (cb - 128)
+ * are an integer plus a multiple of 1/500 resp. 1/250: such a sum is never close enough
+ * to an integer from below for the double or the float rounding to reach it, so
+ * truncating the rounded sum equals y + floor(product) for every non-negative result,
+ * and negative results clamp to 0 either way.  (Checked against the compiled reference
+ * for all 65,536 (y, chroma) pairs per channel.) */
+struct __attribute__((aligned(16))) ChromaRow {
+    double g;
+    int32_t o;
+    int32_t pad_;
+};
+
+__device__ __forceinline__ int32_t floor_div(int32_t num, int32_t den) {   /* den > 0 */
+    const int32_t q = num / den;
+    return q - ((num % den != 0 && num < 0) ? 1 : 0);
+}
+
+__device__ __forceinline__ uint32_t ycc_to_rgb24(uint32_t Y, const ChromaRow tcb, const ChromaRow tcr) {
     const double y = (double) Y;
-    const float R = (float) (y + tcr.x);
-    const float G = (float) ((y - tcb.x) - tcr.y);
-    const float B = (float) (y + tcb.y);
-    return store8(R) | (store8(G) << 8) | (store8(B) << 16);
+    const uint32_t R = (uint32_t) min(max((int32_t) Y + tcr.o, 0), 255);
+    const float G = (float) ((y - tcb.g) - tcr.g);
+    const uint32_t B = (uint32_t) min(max((int32_t) Y + tcb.o, 0), 255);
+    return R | (store8(G) << 8) | (B << 16);
 }
 
 /* 12-byte store of four RGB24 pixels (4-byte aligned) */
@@ -166,7 +182,7 @@ __device__ __forceinline__ uint32_t sample_off(uint32_t blk, uint32_t x, uint32_
  * once per patch.  s0, s1, s2: first block slot of each component inside the MCU.
  */
 template <int SH, int SV>
-__device__ __forceinline__ void colour_fast(const uint8_t *s_smp, const double2 *s_tcb, const double2 *s_tcr, uint32_t bpm,
+__device__ __forceinline__ void colour_fast(const uint8_t *s_smp, const ChromaRow *s_tcb, const ChromaRow *s_tcr, uint32_t bpm,
                                             uint32_t s0, uint32_t s1, uint32_t s2, uint32_t tile_w, uint32_t tile_h,
                                             uint32_t px0, uint32_t py0, uint32_t X, uint32_t Y, uint32_t pitch,
                                             uint8_t *rgb) {
@@ -200,7 +216,7 @@ __device__ __forceinline__ void colour_fast(const uint8_t *s_smp, const double2 
             cbw = *cbp;
             crw = *crp;
         }
-        double2 tb[NC], tr[NC];
+        ChromaRow tb[NC], tr[NC];
 #pragma unroll
         for (int i = 0; i < NC; i++) {
             tb[i] = s_tcb[(cbw >> (8 * i)) & 0xFFu];
@@ -231,9 +247,9 @@ __global__ __launch_bounds__(TPB, MJ_IDCT_WAVES) void mj_k_idct_colour(MjDeviceB
     __shared__ __align__(16) uint8_t s_blk[MAXB * COEF_STRIDE];
     __shared__ __align__(16) uint8_t s_tr[TR_BYTES];
     __shared__ __align__(16) uint16_t s_qt[MJ_MAX_COMP][64];
-    double2 *s_tcb = reinterpret_cast<double2 *>(s_tr);
-    double2 *s_tcr = s_tcb + 256;
-    static_assert(2 * 256 * sizeof(double2) <= TR_BYTES, "chroma tables reuse the transpose buffers");
+    ChromaRow *s_tcb = reinterpret_cast<ChromaRow *>(s_tr);
+    ChromaRow *s_tcr = s_tcb + 256;
+    static_assert(2 * 256 * sizeof(ChromaRow) <= TR_BYTES, "chroma tables reuse the transpose buffers");
 
     const uint32_t ii = b.idct_wg_img[blockIdx.x];
     const MjImageDev &im = b.img[ii];
@@ -322,12 +338,20 @@ __global__ __launch_bounds__(TPB, MJ_IDCT_WAVES) void mj_k_idct_colour(MjDeviceB
         }
     }
     __syncthreads();   /* all samples are in place; the transpose buffers are free */
-    if (threadIdx.x < 256) {
-        const double v = (double) (float) threadIdx.x - 128.0;
-        s_tcb[threadIdx.x] = make_double2(0.34414 * v, 1.772 * v);
-    } else if (threadIdx.x < 512) {
-        const double v = (double) (float) (threadIdx.x - 256) - 128.0;
-        s_tcr[threadIdx.x - 256] = make_double2(1.402 * v, 0.71414 * v);
+    {
+        const int32_t vi = (int32_t) (threadIdx.x & 255u) - 128;
+        const double v = (double) vi;
+        ChromaRow row;
+        row.pad_ = 0;
+        if (threadIdx.x < 256) {
+            row.g = 0.34414 * v;
+            row.o = floor_div(443 * vi, 250);    /* 1.772 */
+            s_tcb[threadIdx.x] = row;
+        } else {
+            row.g = 0.71414 * v;
+            row.o = floor_div(701 * vi, 500);    /* 1.402 */
+            s_tcr[threadIdx.x - 256] = row;
+        }
     }
     const uint8_t *s_smp = s_blk;
 

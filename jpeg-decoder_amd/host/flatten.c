@@ -241,9 +241,9 @@ void mj_choose_split(uint64_t raw_len, uint32_t n_ivl, uint32_t *sub_bits, uint3
     uint64_t lane_bits;
     uint32_t g;
     if (avg > (uint64_t) MJ_SEQ_LANES * 4096) {
-        /* long intervals: many sequences per interval, short lanes */
-        lane_bits = 1024;
-        g = 1;
+        /* long intervals: many sequences per interval */
+        lane_bits = 2048;
+        g = 2;
     } else {
         /* one wavefront per interval with a little headroom for uneven intervals */
         lane_bits = (avg + avg / 16 + MJ_SEQ_LANES - 1) / MJ_SEQ_LANES;

@@ -37,3 +37,27 @@ def test_documented_divergence_last_mcu(oracle):
     d = oracle.decode(data)
     assert gold["coefs"].shape[0] == 3 and d.coefs.shape[0] == 4
     assert np.array_equal(d.coefs[:3], gold["coefs"])
+
+
+def test_integer_red_and_blue_equal_the_float_path(oracle):
+    """The colour kernel computes R and B as y + floor(1.402 (cr - 128)) and
+    y + floor(1.772 (cb - 128)), clamped, instead of the reference's double sum, float
+    rounding and truncation (colour_conversion.c:71-79).  All 65,536 (y, chroma) pairs
+    per channel must agree with the checker."""
+    yy, cc = np.meshgrid(np.arange(256, dtype=np.uint8), np.arange(256, dtype=np.uint8), indexing="ij")
+    y, c = yy.ravel(), cc.ravel()
+    mid = np.full_like(y, 128)
+
+    def rows(a, b, d):
+        return np.concatenate([oracle.ycbcr_row(a[i:i + 32768], b[i:i + 32768], d[i:i + 32768])
+                               for i in range(0, a.size, 32768)])
+
+    w = c.astype(int) - 128
+    red = rows(y, mid, c)[:, 0].astype(int)
+    blue = rows(y, c, mid)[:, 2].astype(int)
+    assert np.array_equal(red, np.clip(y.astype(int) + np.floor_divide(701 * w, 500), 0, 255))
+    assert np.array_equal(blue, np.clip(y.astype(int) + np.floor_divide(443 * w, 250), 0, 255))
+    # and neither depends on the other chroma sample
+    other = (c[::-1]).copy()
+    assert np.array_equal(rows(y, other, c)[:, 0].astype(int), red)
+    assert np.array_equal(rows(y, c, other)[:, 2].astype(int), blue)
