@@ -144,19 +144,20 @@ MJ_HD MjQuad mj_load_quad(const MjScanCtx &cx, uint32_t block) {
 /* Decoder state of one lane.  (p, k, c) is the state proper -- equal (p, k, c)
  * decode identically from there on; the rest is derived from it.
  *
- * Stream words reach the window through a queue of three 16-byte blocks: qa and qb
- * are complete and are what mj_refill takes words from; qc is in flight.  Loads are
- * issued only in mj_checkpoint, which the caller runs every few symbols for the whole
- * wavefront at once: the memory counter a wavefront waits on is in order, so a load
- * issued for one lane between two symbols would stall every lane that needs its own,
- * older data in the next one. */
+ * Stream words reach the window through a queue of 16-byte blocks: qa and qb are what
+ * mj_refill takes words from, qc follows them, nq is in flight.  Loads are issued only
+ * in mj_checkpoint, which the caller runs every MJ_CHECK_EVERY symbols for the whole
+ * wavefront at once, and what a checkpoint requests is not looked at before the next
+ * one: the memory counter a wavefront waits on is in order, and any use of a register
+ * still being loaded -- a copy the compiler inserts is enough -- stalls every lane. */
 struct MjLane {
     uint32_t hi, lo;    /* the stream from bit p on, left-aligned in hi:lo, zero beyond the window */
     uint32_t p;         /* bit offset of the next symbol */
     uint32_t thr;       /* the window ends at bit thr + 32: more than 32 bits are left while p < thr */
     MjQuad qa, qb;      /* the 32 bytes the next words come from */
     uint32_t icur;      /* index (0..7) of the next word in qa:qb */
-    MjQuad qc;          /* the following 16 bytes, requested at a checkpoint */
+    MjQuad qc;          /* the following 16 bytes */
+    MjQuad nq;          /* the 16 bytes after qc, requested at the last checkpoint */
     uint32_t blk16;     /* index of the 16-byte block held in qc */
     uint32_t k;         /* zigzag index of the next coefficient; 0: the DC symbol comes next */
     uint32_t c;         /* block slot inside the MCU */
@@ -179,16 +180,18 @@ MJ_HD uint32_t mj_take_word(MjLane &L) {
     return mj_be32((i & 4u) ? b : a);
 }
 
-/* Keep the queue ahead of the window: once qa is used up, move on by 16 bytes and
- * request the next block. */
+/* Keep the queue ahead of the window: once qa is used up, move on by 16 bytes; then
+ * request the block after qc again, every lane, whether it moved or not -- a request
+ * that depends on nothing can be issued without touching the previous one's data. */
 MJ_HD void mj_checkpoint(const MjScanCtx &cx, MjLane &L) {
     if (L.icur >= 4) {
         L.qa = L.qb;
         L.qb = L.qc;
+        L.qc = L.nq;
         L.icur -= 4;
         L.blk16++;
-        L.qc = mj_load_quad(cx, L.blk16);
     }
+    L.nq = mj_load_quad(cx, L.blk16 + 1);
 }
 
 MJ_HD void mj_lane_init(const MjScanCtx &cx, MjLane &L, uint32_t p, uint32_t k, uint32_t c) {
@@ -198,6 +201,7 @@ MJ_HD void mj_lane_init(const MjScanCtx &cx, MjLane &L, uint32_t p, uint32_t k, 
     L.qb = mj_load_quad(cx, L.blk16 + 1);
     L.blk16 += 2;
     L.qc = mj_load_quad(cx, L.blk16);
+    L.nq = mj_load_quad(cx, L.blk16 + 1);
     L.icur = wi & 3u;
     const uint32_t w0 = mj_take_word(L), w1 = mj_take_word(L);
     L.hi = sh ? mj_align(w0, w1, 32u - sh) : w0;
@@ -366,17 +370,22 @@ MJ_HD MjSym mj_step(const MjScanCtx &cx, MjLane &L, ACC &acc, uint32_t &nb, uint
 /*
  * Decode symbols with an initialised lane until its position reaches `end`, counting
  * only: nb is advanced by the number of blocks completed and every DC difference is
- * added to its component's accumulator.  The lane can go on to the next span as it is.
+ * added to its component's accumulator (MjAccMem or MjAccReg).  The lane can go on to
+ * the next span as it is.
  */
-MJ_HD void mj_run_span(const MjScanCtx &cx, MjLane &L, uint32_t end, uint32_t &nb, int32_t *acc, uint32_t stride) {
-    uint32_t it = 0;
-    MjAccMem am = {acc, stride};
+template <class ACC>
+MJ_HD void mj_run_span(const MjScanCtx &cx, MjLane &L, uint32_t end, uint32_t &nb, ACC &acc) {
     while (L.p < end) {
-        if ((it++ % MJ_CHECK_EVERY) == 0) {
-            mj_checkpoint(cx, L);
+        mj_checkpoint(cx, L);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int i = 0; i < MJ_CHECK_EVERY; i++) {
+            if (L.p < end) {
+                mj_refill(L);
+                (void) mj_step<false>(cx, L, acc, nb, end);
+            }
         }
-        mj_refill(L);
-        (void) mj_step<false>(cx, L, am, nb, end);
     }
 }
 
@@ -388,7 +397,8 @@ MJ_HD void mj_decode_span(const MjScanCtx &cx, uint32_t &p, uint32_t &k, uint32_
     }
     MjLane L;
     mj_lane_init(cx, L, p, k, c);
-    mj_run_span(cx, L, end, nb, acc, stride);
+    MjAccMem am = {acc, stride};
+    mj_run_span(cx, L, end, nb, am);
     p = L.p;
     k = L.k;
     c = L.c;

@@ -117,34 +117,31 @@ struct LaneRec {      /* what a lane knows about one subsequence */
     int32_t d0, d1, d2, d3;
 };
 
-/* Decode with an initialised lane up to `end`; acc: this lane's accumulators, acc[comp * 64] */
-__device__ __forceinline__ LaneRec run_nowrite(const MjScanCtx &cx, MjLane &L, uint32_t end, int32_t *acc) {
+/* Decode with an initialised lane up to `end`, counting blocks and DC differences */
+__device__ __forceinline__ LaneRec run_nowrite(const MjScanCtx &cx, MjLane &L, uint32_t end) {
     uint32_t nb = 0;
-    acc[0] = 0;
-    acc[64] = 0;
-    acc[128] = 0;
-    acc[192] = 0;
-    mj_run_span(cx, L, end, nb, acc, 64);
+    MjAccReg acc = {0, 0, 0, 0};
+    mj_run_span(cx, L, end, nb, acc);
     LaneRec r;
     r.p = L.p;
     r.kc = (L.c << 8) | L.k;
     r.nb = nb;
-    r.d0 = acc[0];
-    r.d1 = acc[64];
-    r.d2 = acc[128];
-    r.d3 = acc[192];
+    r.d0 = acc.d0;
+    r.d1 = acc.d1;
+    r.d2 = acc.d2;
+    r.d3 = acc.d3;
     return r;
 }
 
 /* the same from a bare state */
-__device__ __forceinline__ LaneRec decode_nowrite(const MjScanCtx &cx, uint32_t p, uint32_t kc, uint32_t end, int32_t *acc) {
+__device__ __forceinline__ LaneRec decode_nowrite(const MjScanCtx &cx, uint32_t p, uint32_t kc, uint32_t end) {
     if (p >= end) {
         const LaneRec r = {p, kc, 0, 0, 0, 0, 0};
         return r;
     }
     MjLane L;
     mj_lane_init(cx, L, p, kc & 0xFFu, kc >> 8);
-    return run_nowrite(cx, L, end, acc);
+    return run_nowrite(cx, L, end);
 }
 
 __device__ __forceinline__ void store_rec(MjSubRec *dst, const LaneRec &r) {
@@ -210,15 +207,15 @@ __device__ __forceinline__ void push_task(bool have, uint32_t p, uint32_t packed
     if (have) queue[base + __popcll(mask & ((1ull << lane) - 1ull))] = make_uint2(p, packed);
 }
 
-__global__ __launch_bounds__(SYNC_TPB) void mj_k_entropy_sync(MjDeviceBatch b) {
+__global__ __launch_bounds__(SYNC_TPB, 8) void mj_k_entropy_sync(MjDeviceBatch b) {
     const uint32_t ii = b.wg_img[blockIdx.x];
     const MjImageDev &im = b.img[ii];
     const uint32_t n_seq = b.dyn[ii].n_seq;
     const uint32_t seq0 = (blockIdx.x - im.wg_first) * SYNC_WAVES;
     if (seq0 >= n_seq) return;
 
-    /* dynamic LDS: [tables][DC accumulators][sequence geometry][3 queue counters][2 queues][symbol-run tables] */
-    SeqGeo *s_geo = reinterpret_cast<SeqGeo *>(lds_after_dc(b, SYNC_WAVES));
+    /* dynamic LDS: [tables][sequence geometry][3 queue counters][2 queues][symbol-run tables] */
+    SeqGeo *s_geo = reinterpret_cast<SeqGeo *>(lds_after_dc(b, 0));
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_geo + SYNC_WAVES);
     uint2 *s_queue = reinterpret_cast<uint2 *>(s_cnt + 4);
     unsigned char *s_pairs = reinterpret_cast<unsigned char *>(s_queue + 2 * SYNC_TPB);
@@ -246,7 +243,6 @@ __global__ __launch_bounds__(SYNC_TPB) void mj_k_entropy_sync(MjDeviceBatch b) {
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
     const MjScanCtx cx = make_ctx(b, im, s_pairs);
-    int32_t *acc = lds_dc(b) + wave * 64 * MJ_MAX_COMP + lane;
 
     /* cold pass: the lane's subsequences back to back from a cold state at its first
      * (exact for the first lane of an interval), one record after each */
@@ -261,7 +257,7 @@ __global__ __launch_bounds__(SYNC_TPB) void mj_k_entropy_sync(MjDeviceBatch b) {
             mj_lane_init(cx, L, g.b0 + j0 * S, 0, 0);
             for (uint32_t q = 0; q < G; q++) {
                 if (u0 + q < g.n) {
-                    const LaneRec r = run_nowrite(cx, L, sub_end(g.b0, g.b1, g.nsub, j0 + q, S), acc);
+                    const LaneRec r = run_nowrite(cx, L, sub_end(g.b0, g.b1, g.nsub, j0 + q, S));
                     store_rec(b.rec + g.rec_base + u0 + q, r);
                 }
             }
@@ -281,6 +277,10 @@ __global__ __launch_bounds__(SYNC_TPB) void mj_k_entropy_sync(MjDeviceBatch b) {
     for (;;) {
         const uint32_t total = s_cnt[ci];
         if (total == 0 || (b.dbg & 2u) || (max_rounds && rounds >= max_rounds)) break;
+        /* the number of decoders left never grows, so a wavefront that has none now will
+         * get none later: it leaves, and its slot goes to a workgroup still waiting to
+         * start (a barrier only counts the wavefronts that are still there) */
+        if (wave != 0 && wave * 64 >= total) return;
         const uint32_t cn = (ci == 2) ? 0 : ci + 1, cz = (cn == 2) ? 0 : cn + 1;
         if (threadIdx.x == 0) s_cnt[cz] = 0;
         const uint2 *qin = s_queue + (rounds & 1u) * SYNC_TPB;
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(SYNC_TPB) void mj_k_entropy_sync(MjDeviceBatch b) {
                 const SeqGeo g = s_geo[sw];
                 MjSubRec *dst = b.rec + g.rec_base + u;
                 const MjState old = dst->exit;
-                const LaneRec r = decode_nowrite(cx, tk.x, tk.y & 0xFFFu, sub_end(g.b0, g.b1, g.nsub, g.first + u, S), acc);
+                const LaneRec r = decode_nowrite(cx, tk.x, tk.y & 0xFFFu, sub_end(g.b0, g.b1, g.nsub, g.first + u, S));
                 store_rec(dst, r);
                 more = !(r.p == old.p && r.kc == old.kc) && (u + 1 < g.n);
                 tp = r.p;
@@ -331,11 +331,10 @@ __global__ __launch_bounds__(FIX_TPB) void mj_k_entropy_fix(MjDeviceBatch b) {
     const uint32_t S = im.sub_bits, SQ = MJ_SEQ_LANES * im.lane_subs;
     const Geo g = interval_geo(b.ivl_start + im.ivl_off, iv, S, SQ);
     const uint32_t seq_first = im.seq_off + b.ivl_seq[im.ivl_off + iv]; /* global slot of the interval's first sequence */
-    unsigned char *s_pairs = lds_after_dc(b, FIX_TPB / 64);
+    unsigned char *s_pairs = lds_after_dc(b, 0);
     load_tables(b, im, s_pairs, true);
     __syncthreads();
     const MjScanCtx cx = make_ctx(b, im, s_pairs);
-    int32_t *fix_acc = lds_dc(b) + (threadIdx.x >> 6) * 64 * MJ_MAX_COMP + (threadIdx.x & 63);
     MjSubRec *rec = b.rec + im.rec_off + (uint64_t) b.ivl_seq[im.ivl_off + iv] * SQ;
 
     /* Boundary q (1 <= q < nseq): the decoder that leaves sequence q-1 continues
@@ -365,7 +364,7 @@ __global__ __launch_bounds__(FIX_TPB) void mj_k_entropy_fix(MjDeviceBatch b) {
             const uint32_t first = q * SQ;
             const uint32_t n = min(g.nsub - first, (uint32_t) SQ);
             for (uint32_t l = 0; l < n; l++) {
-                const LaneRec o = decode_nowrite(cx, p, kc, sub_end(g.b0, g.b1, g.nsub, first + l, S), fix_acc);
+                const LaneRec o = decode_nowrite(cx, p, kc, sub_end(g.b0, g.b1, g.nsub, first + l, S));
                 MjSubRec *dst = rec + (uint64_t) first + l;
                 const MjState old = dst->exit;
                 store_rec(dst, o);
@@ -539,32 +538,35 @@ __global__ __launch_bounds__(TPB) void mj_k_entropy_write(MjDeviceBatch b) {
     MjLane L;
     bool live = valid && mj_write_live(p, k, skip, end, g.b1);
     if (live) mj_lane_init(cx, L, p, k, c);
-    for (uint32_t it = 0; __any(live); it++) {
-        bool fin = false;
-        uint32_t fin_blk = 0;
-        if (live && (it % MJ_CHECK_EVERY) == 0) mj_checkpoint(cx, L);
-        if (live) {
-            mj_write_step(cx, L, skip, blk, blk_end, acc, blkbuf, fin, fin_blk);
-            live = mj_write_live(L.p, L.k, skip, end, g.b1);
-        }
-        const unsigned long long mask = __ballot(fin);
-        if (mask) {
-            /* finished blocks leave as whole lines: 8 lanes x 16 bytes per block */
-            const uint32_t rank = __popcll(mask & ((1ull << lane) - 1ull));
-            if (fin) {
-                list_blk[rank] = fin_blk;
-                list_lane[rank] = lane;
+    while (__any(live)) {
+        if (live) mj_checkpoint(cx, L);
+#pragma unroll
+        for (int step = 0; step < MJ_CHECK_EVERY; step++) {
+            bool fin = false;
+            uint32_t fin_blk = 0;
+            if (live) {
+                mj_write_step(cx, L, skip, blk, blk_end, acc, blkbuf, fin, fin_blk);
+                live = mj_write_live(L.p, L.k, skip, end, g.b1);
             }
-            const uint32_t cnt = __popcll(mask);
-            for (uint32_t i0 = 0; i0 < cnt; i0 += 8) {
-                const uint32_t idx = i0 + (lane >> 3);
-                if (idx < cnt) {
-                    const uint32_t src_lane = list_lane[idx], dst_blk = list_blk[idx];
-                    uint4 *src = reinterpret_cast<uint4 *>(const_cast<unsigned char *>(wave_blk) + src_lane * BLK_STRIDE + (lane & 7) * 16);
-                    const uint4 v = *src;
-                    *src = make_uint4(0, 0, 0, 0);
-                    if (dst_blk < store_end) {
-                        *reinterpret_cast<uint4 *>(coef_bytes + (uint64_t) dst_blk * 128 + (lane & 7) * 16) = v;
+            const unsigned long long mask = __ballot(fin);
+            if (mask) {
+                /* finished blocks leave as whole lines: 8 lanes x 16 bytes per block */
+                const uint32_t rank = __popcll(mask & ((1ull << lane) - 1ull));
+                if (fin) {
+                    list_blk[rank] = fin_blk;
+                    list_lane[rank] = lane;
+                }
+                const uint32_t cnt = __popcll(mask);
+                for (uint32_t i0 = 0; i0 < cnt; i0 += 8) {
+                    const uint32_t idx = i0 + (lane >> 3);
+                    if (idx < cnt) {
+                        const uint32_t src_lane = list_lane[idx], dst_blk = list_blk[idx];
+                        uint4 *src = reinterpret_cast<uint4 *>(const_cast<unsigned char *>(wave_blk) + src_lane * BLK_STRIDE + (lane & 7) * 16);
+                        const uint4 v = *src;
+                        *src = make_uint4(0, 0, 0, 0);
+                        if (dst_blk < store_end) {
+                            *reinterpret_cast<uint4 *>(coef_bytes + (uint64_t) dst_blk * 128 + (lane & 7) * 16) = v;
+                        }
                     }
                 }
             }
@@ -612,7 +614,7 @@ static size_t table_lds(const MjDeviceBatch &b, uint32_t waves) {
 hipError_t mj_launch_entropy(const MjDeviceBatch &b, hipStream_t s) {
     if (b.n_entropy_wg == 0) return hipSuccess;
     static const size_t pad = getenv("MJ_TUNE_LDS_PAD") ? (size_t) atol(getenv("MJ_TUNE_LDS_PAD")) : 0;   /* occupancy experiments */
-    const size_t lds = table_lds(b, SYNC_WAVES) + SYNC_WAVES * sizeof(SeqGeo) + 4 * sizeof(uint32_t) + 2 * SYNC_TPB * sizeof(uint2) +
+    const size_t lds = table_lds(b, 0) + SYNC_WAVES * sizeof(SeqGeo) + 4 * sizeof(uint32_t) + 2 * SYNC_TPB * sizeof(uint2) +
                        (size_t) b.max_nac * sizeof(MjHuffPair) + pad;
     hipLaunchKernelGGL(mj_k_entropy_sync, dim3(b.n_entropy_wg), dim3(SYNC_TPB), lds, s, b);
     return hipGetLastError();
@@ -621,7 +623,7 @@ hipError_t mj_launch_entropy(const MjDeviceBatch &b, hipStream_t s) {
 hipError_t mj_launch_entropy_fix(const MjDeviceBatch &b, hipStream_t s) {
     if (b.n_multi_cap == 0 || b.n_entropy_wg == 0) return hipSuccess;
     hipLaunchKernelGGL(mj_k_entropy_fix, dim3(b.n_multi_cap), dim3(FIX_TPB),
-                       table_lds(b, FIX_TPB / 64) + (size_t) b.max_nac * sizeof(MjHuffPair), s, b);
+                       table_lds(b, 0) + (size_t) b.max_nac * sizeof(MjHuffPair), s, b);
     return hipGetLastError();
 }
 
