@@ -176,6 +176,9 @@ __global__ __launch_bounds__(TPB) void mj_k_scan_prefix(MjDeviceBatch b) {
 
 __global__ __launch_bounds__(TPB) void mj_k_scan_write(MjDeviceBatch b) {
     __shared__ uint32_t s_w[TPB / 64];
+    /* the tile's surviving bytes, placed so that LDS offset i goes to the 16-byte aligned
+     * destination address plus i: whole 16-byte pieces then leave with one store */
+    __shared__ __align__(16) uint8_t s_out[MJ_SCAN_TILE + 32];
     const uint32_t tile = blockIdx.x;
     const uint32_t ii = b.tile_img[tile];
     const MjImageDev &im = b.img[ii];
@@ -197,22 +200,38 @@ __global__ __launch_bounds__(TPB) void mj_k_scan_write(MjDeviceBatch b) {
     uint32_t total;
     const uint32_t ex = block_excl_scan(kept | (rst << 16), s_w, &total);
     const MjTileBase tb = b.tile_base[tile];
-    uint32_t out = tb.kept + (ex & 0xFFFFu);
+    uint8_t *dst = b.cmp + im.cmp_off;          /* 16-byte aligned */
+    const uint32_t out0 = tb.kept;               /* first output byte of the tile */
+    const uint32_t skew = out0 & 15u;
+    uint32_t out = skew + (ex & 0xFFFFu);        /* LDS offset of this thread's first surviving byte */
     uint32_t ridx = tb.rst + (ex >> 16);
-    if (pos >= len) return;
-    uint8_t *dst = b.cmp + im.cmp_off;
-    uint32_t *ivl = b.ivl_start + im.ivl_off;
-    const uint4 v = *reinterpret_cast<const uint4 *>(seg + pos);
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    if (pos < len) {
+        uint32_t *ivl = b.ivl_start + im.ivl_off;
+        const uint4 v = *reinterpret_cast<const uint4 *>(seg + pos);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-        const uint32_t c = (cls >> (2 * i)) & 3u;
-        const bool live = pos + i < term;
-        if (live && c == MJ_B_KEEP) {
-            dst[out++] = (uint8_t) ((w[i >> 2] >> (8 * (i & 3))) & 0xFFu);
-        } else if (live && c == MJ_B_RST) {
-            ridx++;
-            if (ridx < im.n_ivl) ivl[ridx] = out; /* interval ridx starts at the next surviving byte */
+        for (int i = 0; i < 16; i++) {
+            const uint32_t c = (cls >> (2 * i)) & 3u;
+            const bool live = pos + i < term;
+            if (live && c == MJ_B_KEEP) {
+                s_out[out++] = (uint8_t) ((w[i >> 2] >> (8 * (i & 3))) & 0xFFu);
+            } else if (live && c == MJ_B_RST) {
+                ridx++;
+                if (ridx < im.n_ivl) ivl[ridx] = out0 - skew + out; /* interval ridx starts at the next surviving byte */
+            }
+        }
+    }
+    __syncthreads();
+    /* copy out: LDS [skew, skew + n) -> dst [out0, out0 + n); piece j covers LDS [16j, 16j + 16) */
+    const uint32_t n = total & 0xFFFFu;
+    const uint32_t lo = skew, hi = skew + n;
+    uint8_t *base = dst + (out0 - skew);
+    for (uint32_t j = threadIdx.x; j * 16 < hi; j += TPB) {
+        const uint32_t a = j * 16, e = a + 16;
+        if (a >= lo && e <= hi) {
+            *reinterpret_cast<uint4 *>(base + a) = *reinterpret_cast<const uint4 *>(s_out + a);
+        } else {
+            for (uint32_t k = (a > lo ? a : lo); k < (e < hi ? e : hi); k++) base[k] = s_out[k];
         }
     }
 }
