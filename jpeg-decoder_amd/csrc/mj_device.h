@@ -63,15 +63,21 @@ typedef struct {
 
 /* Runs of AC symbols that one first-level lookup resolves at once, for the passes that
  * only count (no coefficient values): entry i describes the longest run of two or more
- * whole symbols whose codes lie inside the MJ_LUT_BITS bits i (value bits may stick
+ * whole symbols whose codes lie inside the MJ_RUN_BITS bits i (value bits may stick
  * out), ending at the latest with an end of block:
  *   bits 15-11  bits the run consumes
  *   bits 10-7   zigzag steps of all its symbols but the last (at most 15)
  *   bits 6-0    zigzag step of the last symbol (64 for end of block)
  * 0 = no such run.  The run may be taken only if the block does not end before its
  * last symbol, i.e. k + (bits 10-7) < 64. */
+#define MJ_RUN_BITS 12
+#define MJ_RUN_SIZE (1 << MJ_RUN_BITS)
 typedef struct {
-    uint16_t pair[MJ_LUT_SIZE];
+    uint16_t run[MJ_RUN_SIZE];    /* indexed by the next MJ_RUN_BITS bits */
+} MjHuffRun;
+
+typedef struct {
+    uint16_t pair[MJ_LUT_SIZE];   /* indexed like the first-level lookup */
 } MjHuffPair;
 
 /* The tables one scan uses.  AC tables come first (indices 0 .. nac-1), DC tables after
@@ -82,7 +88,7 @@ typedef struct {
     uint32_t pad_[2];
     MjHuffDev tab[MJ_MAX_TABS];
     MjHuffWalk walk[MJ_MAX_TABS];
-    MjHuffPair pair[MJ_MAX_TABS / 2];   /* counting passes: runs of whole AC symbols */
+    MjHuffRun run[MJ_MAX_TABS / 2];     /* counting passes: runs of whole AC symbols */
     MjHuffPair next[MJ_MAX_TABS / 2];   /* writing pass: lookup entry of the AC symbol that follows the one the index
                                            starts with, when its code lies inside the index bits too; 0 = none */
 } MjHuffSet;

@@ -119,11 +119,13 @@ int64_t mj_emu_decode_coefs(const uint8_t *file, size_t len, int16_t *coefs, int
     mj_ctx_slots(cx, img.bpm, img.blk_comp, img.blk_dc, img.blk_ac);
     cx.tabs = (const unsigned char *) set->tab;
     cx.walk = set->walk;
-    cx.pairs = (const unsigned char *) set->pair;
+    cx.pairs = (const unsigned char *) set->run;
+    cx.pair_stride = (uint32_t) sizeof(MjHuffRun);
     cx.coefs = coefs;
     cx.wi_mask = 0xFFFFFFFFu;
     MjScanCtx wcx = cx;   /* the writing pass looks up second symbols, not runs */
     wcx.pairs = (const unsigned char *) set->next;
+    wcx.pair_stride = (uint32_t) sizeof(MjHuffPair);
 
     int64_t st_subs = 0, st_rounds = 0, st_maxr = 0, st_seqs = 0, st_multi = 0, st_fix = 0, st_tasks = 0;
     // MJ_EMU_HIST=1: print, per round, how many decoders are still out of step

@@ -42,8 +42,9 @@ struct MjScanCtx {
     const uint32_t *stream;      /* the image's compacted stream, 32-bit words in file byte order; 16-byte aligned on the device */
     const unsigned char *tabs;   /* the image's MjHuffDev array (LDS on the device) */
     const MjHuffWalk *walk;      /* the matching canonical ranges (HBM on the device) */
-    const unsigned char *pairs;  /* MjHuffPair per AC table (LDS on the device): the runs for the counting passes, or the
-                                    second-symbol entries for the writing pass */
+    const unsigned char *pairs;  /* one side table per AC table (LDS on the device): MjHuffRun for the counting passes,
+                                    MjHuffPair (second-symbol entries) for the writing pass */
+    uint32_t pair_stride;        /* sizeof of that side table */
     uint32_t slotw0, slotw1, slotw2; /* mj_slot_desc() of slot i in byte i & 3 of word i >> 2 (separate members: never indexed) */
     int16_t *coefs;              /* block 0 of the image; 64 int16 per block, zigzag order */
     uint32_t bpm;                /* blocks per MCU */
@@ -212,7 +213,7 @@ MJ_HD void mj_lane_init(const MjScanCtx &cx, MjLane &L, uint32_t p, uint32_t k, 
     L.c = c;
     L.slot = mj_slot_of(cx, c);
     L.tcur = k ? mj_slot_tac(L.slot) : mj_slot_tdc(L.slot);
-    L.pcur = (L.slot >> 5) * (uint32_t) sizeof(MjHuffPair);
+    L.pcur = mj_mul24(L.slot >> 5, cx.pair_stride);
 }
 
 /* Top the window up to more than 32 bits. */
@@ -301,7 +302,7 @@ MJ_HD MjSym mj_step(const MjScanCtx &cx, MjLane &L, ACC &acc, uint32_t &nb, uint
     MjSym s;
     const uint32_t idx2 = (L.hi >> (32 - MJ_LUT_BITS)) << 1;
     uint32_t e = *reinterpret_cast<const uint16_t *>(cx.tabs + L.tcur + idx2);
-    const uint32_t d = *reinterpret_cast<const uint16_t *>(cx.pairs + L.pcur + idx2);
+    const uint32_t d = *reinterpret_cast<const uint16_t *>(cx.pairs + L.pcur + (WRITE ? idx2 : ((L.hi >> (32 - MJ_RUN_BITS)) << 1)));
     if (MJ_E_LEN(e) == 0) {
         e = mj_long_code(cx, L, e);
     }
@@ -361,7 +362,7 @@ MJ_HD MjSym mj_step(const MjScanCtx &cx, MjLane &L, ACC &acc, uint32_t &nb, uint
         L.c = (L.c + 1 == cx.bpm) ? 0 : L.c + 1;
         L.slot = mj_slot_of(cx, L.c);
         L.tcur = mj_slot_tdc(L.slot);
-        L.pcur = (L.slot >> 5) * (uint32_t) sizeof(MjHuffPair);
+        L.pcur = mj_mul24(L.slot >> 5, cx.pair_stride);
         nb++;
     }
     return s;

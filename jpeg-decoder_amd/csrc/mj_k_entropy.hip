@@ -94,18 +94,19 @@ __device__ __forceinline__ void load_tables(const MjDeviceBatch &b, const MjImag
     const uint4 *src = reinterpret_cast<const uint4 *>(set.tab);
     uint4 *dst = reinterpret_cast<uint4 *>(s_dyn);
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
-    const uint32_t np = set.nac * (uint32_t) (sizeof(MjHuffPair) / 16);
-    const uint4 *psrc = reinterpret_cast<const uint4 *>(runs ? set.pair : set.next);
+    const uint32_t np = set.nac * (uint32_t) ((runs ? sizeof(MjHuffRun) : sizeof(MjHuffPair)) / 16);
+    const uint4 *psrc = runs ? reinterpret_cast<const uint4 *>(set.run) : reinterpret_cast<const uint4 *>(set.next);
     uint4 *pdst = reinterpret_cast<uint4 *>(pairs);
     for (uint32_t i = threadIdx.x; i < np; i += blockDim.x) pdst[i] = psrc[i];
 }
 
-__device__ __forceinline__ MjScanCtx make_ctx(const MjDeviceBatch &b, const MjImageDev &im, const unsigned char *pairs) {
+__device__ __forceinline__ MjScanCtx make_ctx(const MjDeviceBatch &b, const MjImageDev &im, const unsigned char *pairs, bool runs) {
     MjScanCtx cx;
     cx.stream = reinterpret_cast<const uint32_t *>(b.cmp + im.cmp_off);
     cx.tabs = s_dyn;
     cx.walk = b.sets[im.huff_set].walk;
     cx.pairs = pairs;
+    cx.pair_stride = runs ? (uint32_t) sizeof(MjHuffRun) : (uint32_t) sizeof(MjHuffPair);
     mj_ctx_slots(cx, im.bpm, im.blk_comp, im.blk_dc, im.blk_ac);
     cx.coefs = b.coefs + im.coef_off * 64;
     cx.wi_mask = (b.dbg & 32u) ? 15u : 0xFFFFFFFFu;
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(SYNC_TPB, 8) void mj_k_entropy_sync(MjDeviceBatch b
 
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
-    const MjScanCtx cx = make_ctx(b, im, s_pairs);
+    const MjScanCtx cx = make_ctx(b, im, s_pairs, true);
 
     /* cold pass: the lane's subsequences back to back from a cold state at its first
      * (exact for the first lane of an interval), one record after each */
@@ -334,7 +335,7 @@ __global__ __launch_bounds__(FIX_TPB) void mj_k_entropy_fix(MjDeviceBatch b) {
     unsigned char *s_pairs = lds_after_dc(b, 0);
     load_tables(b, im, s_pairs, true);
     __syncthreads();
-    const MjScanCtx cx = make_ctx(b, im, s_pairs);
+    const MjScanCtx cx = make_ctx(b, im, s_pairs, true);
     MjSubRec *rec = b.rec + im.rec_off + (uint64_t) b.ivl_seq[im.ivl_off + iv] * SQ;
 
     /* Boundary q (1 <= q < nseq): the decoder that leaves sequence q-1 continues
@@ -482,7 +483,7 @@ __global__ __launch_bounds__(TPB) void mj_k_entropy_write(MjDeviceBatch b) {
     const uint32_t first = b.seq_sub[im.seq_off + seq];
     const Geo g = interval_geo(b.ivl_start + im.ivl_off, iv, S, SQ);
     const uint32_t n = min(g.nsub - first, SQ);
-    const MjScanCtx cx = make_ctx(b, im, s_next);
+    const MjScanCtx cx = make_ctx(b, im, s_next, false);
     /* the lane's subsequences: u0 .. u0 + cnt - 1 of the sequence */
     const uint32_t u0 = lane * G;
     const bool valid = u0 < n;
@@ -583,7 +584,7 @@ __global__ __launch_bounds__(TPB) void mj_k_entropy_serial(MjDeviceBatch b) {
     unsigned char *s_next = lds_after_dc(b, WAVES);
     load_tables(b, im, s_next, false);
     __syncthreads();
-    const MjScanCtx cx = make_ctx(b, im, s_next);
+    const MjScanCtx cx = make_ctx(b, im, s_next, false);
     const uint32_t *ivl = b.ivl_start + im.ivl_off;
     const uint32_t n_blocks = im.n_mcu * im.bpm;
     for (uint32_t iv = threadIdx.x; iv < im.n_ivl; iv += TPB) {
@@ -615,7 +616,7 @@ hipError_t mj_launch_entropy(const MjDeviceBatch &b, hipStream_t s) {
     if (b.n_entropy_wg == 0) return hipSuccess;
     static const size_t pad = getenv("MJ_TUNE_LDS_PAD") ? (size_t) atol(getenv("MJ_TUNE_LDS_PAD")) : 0;   /* occupancy experiments */
     const size_t lds = table_lds(b, 0) + SYNC_WAVES * sizeof(SeqGeo) + 4 * sizeof(uint32_t) + 2 * SYNC_TPB * sizeof(uint2) +
-                       (size_t) b.max_nac * sizeof(MjHuffPair) + pad;
+                       (size_t) b.max_nac * sizeof(MjHuffRun) + pad;
     hipLaunchKernelGGL(mj_k_entropy_sync, dim3(b.n_entropy_wg), dim3(SYNC_TPB), lds, s, b);
     return hipGetLastError();
 }
@@ -623,7 +624,7 @@ hipError_t mj_launch_entropy(const MjDeviceBatch &b, hipStream_t s) {
 hipError_t mj_launch_entropy_fix(const MjDeviceBatch &b, hipStream_t s) {
     if (b.n_multi_cap == 0 || b.n_entropy_wg == 0) return hipSuccess;
     hipLaunchKernelGGL(mj_k_entropy_fix, dim3(b.n_multi_cap), dim3(FIX_TPB),
-                       table_lds(b, 0) + (size_t) b.max_nac * sizeof(MjHuffPair), s, b);
+                       table_lds(b, 0) + (size_t) b.max_nac * sizeof(MjHuffRun), s, b);
     return hipGetLastError();
 }
 

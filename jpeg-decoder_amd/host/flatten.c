@@ -121,7 +121,20 @@ void mj_parsed_free(MjParsed *p) {
     memset(p, 0, sizeof *p);
 }
 
-void mj_flatten_huff(const HuffTable *ht, int is_ac, MjHuffDev *out, MjHuffWalk *walk, MjHuffPair *pair, MjHuffPair *next) {
+/* the lookup entry of the code that starts the 16 left-aligned bits w, 0 if it is not
+ * resolved by the two lookup levels */
+static uint32_t entry_of(const MjHuffDev *t, uint32_t w) {
+    uint32_t e = t->lut[(w >> (16 - MJ_LUT_BITS)) & (MJ_LUT_SIZE - 1)];
+    if (MJ_E_LEN(e) != 0) {
+        return e;
+    }
+    if (e & MJ_LUT_LONG) {
+        return t->sub[e & (MJ_SUB_MAX - 1)][w & (MJ_SUB_SIZE - 1)];
+    }
+    return 0;
+}
+
+void mj_flatten_huff(const HuffTable *ht, int is_ac, MjHuffDev *out, MjHuffWalk *walk, MjHuffRun *pair, MjHuffPair *next) {
     memset(out, 0, sizeof *out);
     memset(walk, 0, sizeof *walk);
     if (pair) memset(pair, 0, sizeof *pair);
@@ -189,13 +202,13 @@ void mj_flatten_huff(const HuffTable *ht, int is_ac, MjHuffDev *out, MjHuffWalk 
     if (!is_ac || !pair || !next) {
         return;
     }
-    /* runs of whole symbols inside one first-level index (see MjHuffPair) */
-    for (uint32_t idx = 0; idx < MJ_LUT_SIZE; idx++) {
+    /* runs of whole symbols inside MJ_RUN_BITS bits (see MjHuffRun) */
+    for (uint32_t idx = 0; idx < MJ_RUN_SIZE; idx++) {
         uint32_t pos = 0, n = 0, used = 0, before = 0, last = 0, steps = 0;
-        while (pos < MJ_LUT_BITS) {
-            const uint32_t e = out->lut[(idx << pos) & (MJ_LUT_SIZE - 1)];
+        while (pos < MJ_RUN_BITS) {
+            const uint32_t e = entry_of(out, ((idx << (16 - MJ_RUN_BITS)) << pos) & 0xFFFFu);
             const uint32_t len = MJ_E_LEN(e);
-            if (len == 0 || len > MJ_LUT_BITS - pos) {
+            if (len == 0 || len > MJ_RUN_BITS - pos) {
                 break;   /* a longer code, or one whose bits are not all known */
             }
             if (n >= 1 && steps > 15) {
@@ -212,8 +225,10 @@ void mj_flatten_huff(const HuffTable *ht, int is_ac, MjHuffDev *out, MjHuffWalk 
             }
         }
         if (n >= 2 && used <= 31) {
-            pair->pair[idx] = (uint16_t) ((used << 11) | (before << 7) | last);
+            pair->run[idx] = (uint16_t) ((used << 11) | (before << 7) | last);
         }
+    }
+    for (uint32_t idx = 0; idx < MJ_LUT_SIZE; idx++) {
         /* the symbol after the first one, for the pass that needs every value */
         const uint32_t e1 = out->lut[idx];
         const uint32_t used1 = MJ_E_LEN(e1) + ((e1 >> 7) & 15u);
@@ -340,7 +355,7 @@ int mj_flatten_image(const MjParsed *p, size_t file_len, MjImageDev *img, MjHuff
     }
     for (int t = 0; t < 4; t++) {
         if (ac_slot[t] >= 0) {
-            mj_flatten_huff(&p->hts.DCAC[TC_AC][t], 1, &set->tab[ac_slot[t]], &set->walk[ac_slot[t]], &set->pair[ac_slot[t]],
+            mj_flatten_huff(&p->hts.DCAC[TC_AC][t], 1, &set->tab[ac_slot[t]], &set->walk[ac_slot[t]], &set->run[ac_slot[t]],
                             &set->next[ac_slot[t]]);
         }
         if (dc_slot[t] >= 0) {

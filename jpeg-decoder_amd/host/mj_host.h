@@ -32,7 +32,7 @@ int mj_parse_headers(const uint8_t *buf, size_t len, MjParsed *out, const char *
 void mj_parsed_free(MjParsed *p);
 
 /* huff_table.h:9-14 -> lookup form. */
-void mj_flatten_huff(const HuffTable *ht, int is_ac, MjHuffDev *out, MjHuffWalk *walk, MjHuffPair *pair, MjHuffPair *next);
+void mj_flatten_huff(const HuffTable *ht, int is_ac, MjHuffDev *out, MjHuffWalk *walk, MjHuffRun *pair, MjHuffPair *next);
 
 /* Geometry, per-slot table selection, quantiser tables and the Huffman set of one
  * image.  Batch placement fields are left zero.  0 / -1. */
