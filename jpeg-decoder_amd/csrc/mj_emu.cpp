@@ -72,6 +72,22 @@ bool same_state(const Rec &a, const Rec &b) {
 
 extern "C" {
 
+/* The sixteen-at-a-time byte classifier of the scan kernels, byte by byte for the tests:
+ * out[i] = class (MJ_B_*) of byte pos + i.  buf must be readable up to pos + 16. */
+void mj_emu_classify16(const uint8_t *buf, uint32_t len, uint32_t pos, uint8_t *out) {
+    uint32_t w[4];
+    const MjClass16 c = mj_classify16_at(buf, len, pos, w);
+    for (int i = 0; i < 16; i++) {
+        const uint32_t bit = 1u << (8 * (i & 3) + 7);
+        out[i] = (c.keep[i >> 2] & bit) ? MJ_B_KEEP : (c.rst[i >> 2] & bit) ? MJ_B_RST : (c.term[i >> 2] & bit) ? MJ_B_TERM : MJ_B_DROP;
+    }
+}
+
+/* the byte-at-a-time rule, for comparison */
+int mj_emu_classify(uint32_t prev, uint32_t cur, uint32_t next) {
+    return mj_classify(prev, cur, next);
+}
+
 /*
  * Decode the coefficients of one JPEG file with the emulated kernel algorithm.
  * coefs: n_blocks*64 int16 (caller-allocated, zeroed here).  force_sub_bits: 0 =

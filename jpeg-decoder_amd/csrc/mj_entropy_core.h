@@ -473,4 +473,96 @@ MJ_HD int mj_classify(uint32_t prev, uint32_t cur, uint32_t next) {
     return MJ_B_KEEP;
 }
 
+/* ---- sixteen bytes at a time -------------------------------------------------- */
+
+/* Classes of sixteen consecutive bytes as byte masks: bit 7 of byte j of word i is set
+ * when byte 4 i + j has the class; a byte flagged in none of the three is MJ_B_DROP. */
+struct MjClass16 {
+    uint32_t keep[4], rst[4], term[4];
+};
+
+/* bit 7 of every byte of v that is zero (exact per byte: no carries between bytes) */
+MJ_HD uint32_t mj_zero_bytes(uint32_t v) {
+    return ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v | 0x7F7F7F7Fu);
+}
+
+/* the bytes of word i (of four) that are among the first n of the sixteen, as a mask */
+MJ_HD uint32_t mj_bytes_below(uint32_t n, int i) {
+    const uint32_t m = n > 4u * i ? n - 4u * i : 0u;
+    return m >= 4 ? 0xFFFFFFFFu : (m ? (0xFFFFFFFFu >> (32u - 8u * m)) : 0u);
+}
+
+/* mj_classify for the sixteen bytes w[0..3] (little-endian words) given the byte before
+ * and the byte after them */
+MJ_HD MjClass16 mj_classify16(const uint32_t (&w)[4], uint32_t prev, uint32_t next) {
+    uint32_t ff[4], z0[4], rs[4];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int i = 0; i < 4; i++) {
+        ff[i] = mj_zero_bytes(~w[i]);
+        z0[i] = mj_zero_bytes(w[i]);
+        rs[i] = mj_zero_bytes((w[i] & 0xF8F8F8F8u) ^ 0xD0D0D0D0u);
+    }
+    MjClass16 c;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int i = 0; i < 4; i++) {
+        const uint32_t prev_ff = (ff[i] << 8) | (i ? ff[i - 1] >> 24 : (prev == 0xFFu ? 0x80u : 0u));
+        const uint32_t next_00 = (z0[i] >> 8) | (i < 3 ? z0[i + 1] << 24 : (next == 0x00u ? 0x80000000u : 0u));
+        const uint32_t next_rs = (rs[i] >> 8) | (i < 3 ? rs[i + 1] << 24 : ((next & 0xF8u) == 0xD0u ? 0x80000000u : 0u));
+        const uint32_t next_ff = (ff[i] >> 8) | (i < 3 ? ff[i + 1] << 24 : (next == 0xFFu ? 0x80000000u : 0u));
+        const uint32_t drop1 = prev_ff & (z0[i] | rs[i]);
+        c.keep[i] = ~drop1 & (~ff[i] | next_00) & 0x80808080u;
+        c.rst[i] = ff[i] & next_rs;
+        c.term[i] = ff[i] & ~(next_00 | next_rs | next_ff);
+    }
+    return c;
+}
+
+/* The classes of bytes pos .. pos + 15 of a segment of len bytes (pos a multiple of 16,
+ * pos < len; sixteen bytes are readable at seg + pos).  Bytes at or past the end are
+ * MJ_B_DROP and count as zero for their neighbours.  w gets the bytes. */
+MJ_HD MjClass16 mj_classify16_at(const uint8_t *seg, uint32_t len, uint32_t pos, uint32_t (&w)[4]) {
+    const uint32_t *p32 = reinterpret_cast<const uint32_t *>(seg + pos);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint4 v = *reinterpret_cast<const uint4 *>(p32);
+    w[0] = v.x;
+    w[1] = v.y;
+    w[2] = v.z;
+    w[3] = v.w;
+#else
+    w[0] = p32[0];
+    w[1] = p32[1];
+    w[2] = p32[2];
+    w[3] = p32[3];
+#endif
+    const uint32_t prev = pos ? seg[pos - 1] : 0u;
+    const uint32_t next = (pos + 16 < len) ? seg[pos + 16] : 0u;
+    const uint32_t nvalid = len - pos;     /* >= 1 */
+    uint32_t valid[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    if (nvalid < 16) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int i = 0; i < 4; i++) {
+            valid[i] = mj_bytes_below(nvalid, i);
+            w[i] &= valid[i];
+        }
+    }
+    MjClass16 c = mj_classify16(w, prev, next);
+    if (nvalid < 16) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int i = 0; i < 4; i++) {
+            c.keep[i] &= valid[i];
+            c.rst[i] &= valid[i];
+            c.term[i] &= valid[i];
+        }
+    }
+    return c;
+}
+
 #endif /* MJ_ENTROPY_CORE_H */

@@ -52,27 +52,19 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *s_w /*
     return base + inc - v;
 }
 
-/* Classes of this thread's 16 bytes, 2 bits each (MJ_B_*).  Bytes at or past the
- * end of the segment are reported as MJ_B_DROP. */
-__device__ __forceinline__ uint32_t classify16(const uint8_t *seg, uint32_t len, uint32_t pos) {
-    if (pos >= len) {
-        return 0x55555555u; /* all DROP */
-    }
-    const uint4 v = *reinterpret_cast<const uint4 *>(seg + pos);
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-    uint32_t prev = pos ? seg[pos - 1] : 0u;
-    uint32_t after = (pos + 16 < len) ? seg[pos + 16] : 0u;
-    uint32_t cls = 0;
+/* Classes of this thread's 16 bytes with everything at or past the terminating marker
+ * (raw offset term) removed; kept and rst get the counts of what is left. */
+__device__ __forceinline__ void cut_at(MjClass16 &c, uint32_t pos, uint32_t term, uint32_t &kept, uint32_t &rst) {
+    const uint32_t nlive = term > pos ? min(term - pos, 16u) : 0u;
+    kept = rst = 0;
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-        const uint32_t cur = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-        uint32_t next = (i < 15) ? ((w[(i + 1) >> 2] >> (8 * ((i + 1) & 3))) & 0xFFu) : after;
-        if (pos + i + 1 >= len) next = 0;
-        uint32_t c = (pos + i < len) ? (uint32_t) mj_classify(prev, cur, next) : (uint32_t) MJ_B_DROP;
-        cls |= c << (2 * i);
-        prev = cur;
+    for (int i = 0; i < 4; i++) {
+        const uint32_t live = mj_bytes_below(nlive, i);
+        c.keep[i] &= live;
+        c.rst[i] &= live;
+        kept += __popc(c.keep[i]);
+        rst += __popc(c.rst[i]);
     }
-    return cls;
 }
 
 __global__ __launch_bounds__(TPB) void mj_k_scan_count(MjDeviceBatch b) {
@@ -89,24 +81,22 @@ __global__ __launch_bounds__(TPB) void mj_k_scan_count(MjDeviceBatch b) {
         s_sum[0] = s_sum[1] = 0;
     }
     __syncthreads();
-    const uint32_t cls = classify16(seg, len, pos);
-    /* first terminating marker in the tile */
+    MjClass16 cls = {};
+    uint32_t w[4];
     uint32_t my_term = MJ_NO_TERMINATOR;
+    if (pos < len) {
+        cls = mj_classify16_at(seg, len, pos, w);
+        /* first terminating marker in the tile */
 #pragma unroll
-    for (int i = 15; i >= 0; i--) {
-        if (((cls >> (2 * i)) & 3u) == MJ_B_TERM) my_term = pos + i;
+        for (int i = 3; i >= 0; i--) {
+            if (cls.term[i]) my_term = pos + 4 * i + ((uint32_t) __builtin_ctz(cls.term[i]) >> 3);
+        }
     }
     if (my_term != MJ_NO_TERMINATOR) atomicMin(&s_term, my_term);
     __syncthreads();
     const uint32_t term = s_term;
-    uint32_t kept = 0, rst = 0;
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-        const uint32_t c = (cls >> (2 * i)) & 3u;
-        const bool live = pos + i < term;
-        kept += (live && c == MJ_B_KEEP);
-        rst += (live && c == MJ_B_RST);
-    }
+    uint32_t kept, rst;
+    cut_at(cls, pos, term, kept, rst);
     /* block sums: wave reduce then LDS atomics (4 waves) */
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -188,15 +178,11 @@ __global__ __launch_bounds__(TPB) void mj_k_scan_write(MjDeviceBatch b) {
     const uint32_t len = (uint32_t) im.raw_len;
     const uint8_t *seg = b.raw + im.raw_off;
     const uint32_t pos = tile_pos + threadIdx.x * 16;
-    const uint32_t cls = classify16(seg, len, pos);
-    uint32_t kept = 0, rst = 0;
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-        const uint32_t c = (cls >> (2 * i)) & 3u;
-        const bool live = pos + i < term;
-        kept += (live && c == MJ_B_KEEP);
-        rst += (live && c == MJ_B_RST);
-    }
+    MjClass16 cls = {};
+    uint32_t w[4] = {0, 0, 0, 0};
+    if (pos < len) cls = mj_classify16_at(seg, len, pos, w);
+    uint32_t kept, rst;
+    cut_at(cls, pos, term, kept, rst);
     uint32_t total;
     const uint32_t ex = block_excl_scan(kept | (rst << 16), s_w, &total);
     const MjTileBase tb = b.tile_base[tile];
@@ -205,17 +191,14 @@ __global__ __launch_bounds__(TPB) void mj_k_scan_write(MjDeviceBatch b) {
     const uint32_t skew = out0 & 15u;
     uint32_t out = skew + (ex & 0xFFFFu);        /* LDS offset of this thread's first surviving byte */
     uint32_t ridx = tb.rst + (ex >> 16);
-    if (pos < len) {
+    if (kept | rst) {
         uint32_t *ivl = b.ivl_start + im.ivl_off;
-        const uint4 v = *reinterpret_cast<const uint4 *>(seg + pos);
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int i = 0; i < 16; i++) {
-            const uint32_t c = (cls >> (2 * i)) & 3u;
-            const bool live = pos + i < term;
-            if (live && c == MJ_B_KEEP) {
+            const uint32_t bit = 1u << (8 * (i & 3) + 7);
+            if (cls.keep[i >> 2] & bit) {
                 s_out[out++] = (uint8_t) ((w[i >> 2] >> (8 * (i & 3))) & 0xFFu);
-            } else if (live && c == MJ_B_RST) {
+            } else if (cls.rst[i >> 2] & bit) {
                 ridx++;
                 if (ridx < im.n_ivl) ivl[ridx] = out0 - skew + out; /* interval ridx starts at the next surviving byte */
             }

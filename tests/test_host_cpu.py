@@ -94,3 +94,31 @@ def test_synthetic_generator_is_decodable_and_deterministic(oracle):
     g = J.synth.encode_jpeg(img[..., 1].copy(), quality=75, restart_interval=4)
     d = oracle.decode(g)
     assert d.ncs == 1 and np.abs(d.rgb[..., 0].astype(int) - img[..., 1]).mean() < 8.0
+
+
+def test_sixteen_byte_classifier_equals_the_byte_rule():
+    """The scan kernels classify sixteen bytes at a time with byte masks; the result must be
+    the byte-at-a-time rule (bitstream.c:22-59, :84-134, :142-176) on marker-heavy data,
+    including segments that end inside a group of sixteen with other data behind them."""
+    lib = C.CDLL(binding.EMU_PATH)
+    lib.mj_emu_classify16.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    lib.mj_emu_classify.restype = C.c_int
+    rng = np.random.default_rng(7)
+    alphabet = np.array([0xFF, 0xFF, 0xFF, 0x00, 0x00, 0xD0, 0xD3, 0xD7, 0xD8, 0xD9, 0xCF, 0x12, 0x80, 0xFE, 0x01],
+                        np.uint8)
+    out = np.zeros(16, np.uint8)
+    for _ in range(600):
+        n = int(rng.integers(1, 120))
+        buf = rng.integers(0, 256, ((n + 15) // 16) * 16 + 32).astype(np.uint8)
+        buf[:n] = alphabet[rng.integers(0, len(alphabet), n)]
+        for pos in range(0, n, 16):
+            lib.mj_emu_classify16(buf.ctypes.data, n, pos, out.ctypes.data)
+            for i in range(16):
+                j = pos + i
+                if j >= n:
+                    want = 1   # MJ_B_DROP
+                else:
+                    prev = int(buf[j - 1]) if j else 0
+                    nxt = int(buf[j + 1]) if j + 1 < n else 0
+                    want = lib.mj_emu_classify(prev, int(buf[j]), nxt)
+                assert want == out[i], (n, j, hex(int(buf[j])))
