@@ -52,7 +52,80 @@ def flat(W, H, rgb):
     return np.broadcast_to(np.array(rgb, np.uint8), (H, W, 3)).copy()
 
 
-# name, image factory, mode, save kwargs
+def segments(data):
+    """Split a JPEG into (marker, payload-with-length-bytes) up to and including SOS; the
+    rest (entropy-coded data .. EOI) is returned as the tail."""
+    assert data[:2] == b"\xff\xd8"
+    out, i = [], 2
+    while True:
+        assert data[i] == 0xFF
+        m = data[i + 1]
+        n = (data[i + 2] << 8) | data[i + 3]
+        out.append((m, data[i + 2:i + 2 + n]))
+        i += 2 + n
+        if m == 0xDA:
+            return out, data[i:]
+
+
+def join(segs, tail):
+    return b"\xff\xd8" + b"".join(bytes([0xFF, m]) + p for m, p in segs) + tail
+
+
+def to_sof1(data, move_tables=False):
+    """Baseline -> extended sequential (FFC1).  move_tables: renumber the Huffman tables
+    0,1 -> 2,3 (only SOF1 may use them, huff_table.c:32-41) in DHT and in the scan header."""
+    segs, tail = segments(data)
+    out = []
+    for m, p in segs:
+        p = bytearray(p)
+        if m == 0xC0:
+            m = 0xC1
+        elif m == 0xC4 and move_tables:
+            i = 2
+            while i < len(p):
+                p[i] = (p[i] & 0xF0) | ((p[i] & 0x0F) + 2)
+                i += 17 + sum(p[i + 1:i + 17])
+        elif m == 0xDA and move_tables:
+            for c in range(p[2]):
+                t = p[4 + 2 * c]
+                p[4 + 2 * c] = (((t >> 4) + 2) << 4) | ((t & 0x0F) + 2)
+        out.append((m, bytes(p)))
+    return join(out, tail)
+
+
+def to_dqt16(data):
+    """Every quantisation table re-written with 16-bit entries (Pq = 1,
+    quant_table.c:110-113), one table per DQT segment."""
+    segs, tail = segments(data)
+    out = []
+    for m, p in segs:
+        if m != 0xDB:
+            out.append((m, p))
+            continue
+        i = 2
+        while i < len(p):
+            assert p[i] >> 4 == 0
+            body = bytes([0x10 | (p[i] & 0x0F)]) + b"".join(bytes([0, v]) for v in p[i + 1:i + 65])
+            out.append((0xDB, (2 + len(body)).to_bytes(2, "big") + body))
+            i += 65
+    return join(out, tail)
+
+
+def with_dnl_and_comments(data):
+    """A comment before the frame header, a reserved-for-extensions segment after it, and a
+    DNL segment (decode.c:346-351) repeating the frame's line count after the scan."""
+    segs, tail = segments(data)
+    out = []
+    for m, p in segs:
+        if m == 0xC0:
+            out.append((0xFE, (2 + 11).to_bytes(2, "big") + b"hello world"))
+            y = p[3:5]
+        out.append((m, p))
+    assert tail[-2:] == b"\xff\xd9"
+    return join(out, tail[:-2] + b"\xff\xdc\x00\x04" + y + b"\xff\xd9")
+
+
+# name, image factory, mode, save kwargs[, transformation of the encoded file]
 FIXTURES = [
     ("c420_q85_64x48", lambda: synth(64, 48, 1), "RGB", dict(quality=85, subsampling="4:2:0")),
     ("c420_q85_100x75_ri3", lambda: synth(100, 75, 2), "RGB", dict(quality=85, subsampling="4:2:0", restart_marker_blocks=3)),
@@ -74,6 +147,14 @@ FIXTURES = [
     ("g_q95_opt_120x88_rirow", lambda: synth(120, 88, 16)[..., 1], "L", dict(quality=95, optimize=True, restart_marker_rows=1)),
     ("g_q75_72x40_ri4", lambda: synth(72, 40, 17)[..., 2], "L", dict(quality=75, restart_marker_blocks=4)),
     ("g_q85_edges_48x48", lambda: edges(48, 48, 18)[..., 0], "L", dict(quality=85)),
+    # container variants: the same entropy coding behind other marker segments
+    ("c420_q85_sof1_64x48", lambda: synth(64, 48, 21), "RGB", dict(quality=85, subsampling="4:2:0"), to_sof1),
+    ("c422_q80_sof1_tabs23_88x40_ri2", lambda: synth(88, 40, 22), "RGB",
+     dict(quality=80, subsampling="4:2:2", optimize=True, restart_marker_blocks=2), lambda d: to_sof1(d, True)),
+    ("c444_q90_dqt16_56x40", lambda: synth(56, 40, 23), "RGB", dict(quality=90, subsampling="4:4:4"), to_dqt16),
+    ("c420_q75_dnl_com_80x48", lambda: synth(80, 48, 24), "RGB", dict(quality=75, subsampling="4:2:0", restart_marker_rows=1),
+     with_dnl_and_comments),
+    ("g_q85_sof1_dqt16_40x24", lambda: synth(40, 24, 25)[..., 0], "L", dict(quality=85), lambda d: to_dqt16(to_sof1(d))),
     # BASELINE config 1: the reference's own CPU-runnable case
     ("C1_c420_q85_512x512", lambda: synth(512, 512, 0), "RGB", dict(quality=85, subsampling="4:2:0")),
 ]
@@ -95,11 +176,13 @@ def main():
     ref = Ref()
     manifest = {"generator": "oracle/gen_fixtures.py", "pillow": Image.__version__, "fixtures": []}
     for group, divergent in ((FIXTURES, False), (DIVERGENT, True)):
-        for name, make, mode, kw in group:
+        for name, make, mode, kw, *post in group:
             arr = make()
             buf = io.BytesIO()
             Image.fromarray(arr, mode).save(buf, "JPEG", **kw)
             data = buf.getvalue()
+            if post:
+                data = post[0](data)
             d = ref.decode(data)
             with open(os.path.join(OUT, name + ".jpg"), "wb") as f:
                 f.write(data)
