@@ -195,17 +195,22 @@ struct SeqGeo {           /* one sequence of the workgroup, in LDS */
     uint32_t pad_[2];
 };
 
-/* A decoder that has to go on: (entry bit position, packed rest).  Packed: bits 0-11
- * (slot << 8) | zigzag index, bits 12-14 sequence within the workgroup, bits 16-25 the
+/* A decoder that has to go on, in one word: bits 0-5 zigzag index, 6-9 block slot, 10-14
+ * how many bits past the start of its next subsequence it stands (a symbol that crosses a
+ * boundary ends at most 30 bits after it), 15-17 sequence within the workgroup, 18-27 the
  * subsequence (within the sequence) to decode next. */
-__device__ __forceinline__ void push_task(bool have, uint32_t p, uint32_t packed, uint2 *queue, uint32_t *count) {
+__device__ __forceinline__ uint32_t pack_task(uint32_t kc, uint32_t over, uint32_t seq, uint32_t u) {
+    return (kc & 63u) | ((kc >> 8) << 6) | (over << 10) | (seq << 15) | (u << 18);
+}
+
+__device__ __forceinline__ void push_task(bool have, uint32_t task, uint32_t *queue, uint32_t *count) {
     const unsigned long long mask = __ballot(have);
     if (mask == 0) return;
     const uint32_t lane = threadIdx.x & 63;
     uint32_t base = 0;
     if (lane == 0) base = atomicAdd(count, (uint32_t) __popcll(mask));
     base = __shfl(base, 0, 64);
-    if (have) queue[base + __popcll(mask & ((1ull << lane) - 1ull))] = make_uint2(p, packed);
+    if (have) queue[base + __popcll(mask & ((1ull << lane) - 1ull))] = task;
 }
 
 __global__ __launch_bounds__(SYNC_TPB, 8) void mj_k_entropy_sync(MjDeviceBatch b) {
@@ -215,11 +220,11 @@ __global__ __launch_bounds__(SYNC_TPB, 8) void mj_k_entropy_sync(MjDeviceBatch b
     const uint32_t seq0 = (blockIdx.x - im.wg_first) * SYNC_WAVES;
     if (seq0 >= n_seq) return;
 
-    /* dynamic LDS: [tables][sequence geometry][3 queue counters][2 queues][symbol-run tables] */
+    /* dynamic LDS: [tables][sequence geometry][3 queue counters][queue][symbol-run tables] */
     SeqGeo *s_geo = reinterpret_cast<SeqGeo *>(lds_after_dc(b, 0));
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_geo + SYNC_WAVES);
-    uint2 *s_queue = reinterpret_cast<uint2 *>(s_cnt + 4);
-    unsigned char *s_pairs = reinterpret_cast<unsigned char *>(s_queue + 2 * SYNC_TPB);
+    uint32_t *s_queue = s_cnt + 4;
+    unsigned char *s_pairs = reinterpret_cast<unsigned char *>(s_queue + SYNC_TPB);
 
     const uint32_t S = im.sub_bits, G = im.lane_subs, SQ = MJ_SEQ_LANES * G;
     load_tables(b, im, s_pairs, true);
@@ -251,7 +256,7 @@ __global__ __launch_bounds__(SYNC_TPB, 8) void mj_k_entropy_sync(MjDeviceBatch b
         const SeqGeo g = s_geo[wave];
         const uint32_t u0 = lane * G;
         bool more = false;
-        uint32_t tp = 0, tkc = 0;
+        uint32_t task = 0;
         if (u0 < g.n) {
             const uint32_t j0 = g.first + u0;
             MjLane L;
@@ -263,10 +268,9 @@ __global__ __launch_bounds__(SYNC_TPB, 8) void mj_k_entropy_sync(MjDeviceBatch b
                 }
             }
             more = (u0 + G < g.n);
-            tp = L.p;
-            tkc = (L.c << 8) | L.k;
+            task = pack_task((L.c << 8) | L.k, L.p - (g.b0 + (j0 + G) * S), wave, u0 + G);
         }
-        push_task(more, tp, tkc | (wave << 12) | ((u0 + G) << 16), s_queue, &s_cnt[0]);
+        push_task(more, task, s_queue, &s_cnt[0]);
     }
     __syncthreads();
 
@@ -284,26 +288,27 @@ __global__ __launch_bounds__(SYNC_TPB, 8) void mj_k_entropy_sync(MjDeviceBatch b
         if (wave != 0 && wave * 64 >= total) return;
         const uint32_t cn = (ci == 2) ? 0 : ci + 1, cz = (cn == 2) ? 0 : cn + 1;
         if (threadIdx.x == 0) s_cnt[cz] = 0;
-        const uint2 *qin = s_queue + (rounds & 1u) * SYNC_TPB;
-        uint2 *qout = s_queue + ((rounds + 1) & 1u) * SYNC_TPB;
         rounds++;
         tasks += total;
+        /* one queue: everybody takes its decoder out before anybody puts one back */
+        const uint32_t tk = (threadIdx.x < total) ? s_queue[threadIdx.x] : 0u;
+        __syncthreads();
         if (wave * 64 < total) {
             bool more = false;
-            uint32_t tp = 0, packed = 0;
+            uint32_t task = 0;
             if (threadIdx.x < total) {
-                const uint2 tk = qin[threadIdx.x];
-                const uint32_t sw = (tk.y >> 12) & 7u, u = tk.y >> 16;
+                const uint32_t sw = (tk >> 15) & 7u, u = tk >> 18;
+                const uint32_t kc = (tk & 63u) | (((tk >> 6) & 15u) << 8);
                 const SeqGeo g = s_geo[sw];
                 MjSubRec *dst = b.rec + g.rec_base + u;
                 const MjState old = dst->exit;
-                const LaneRec r = decode_nowrite(cx, tk.x, tk.y & 0xFFFu, sub_end(g.b0, g.b1, g.nsub, g.first + u, S));
+                const uint32_t start = g.b0 + (g.first + u) * S;
+                const LaneRec r = decode_nowrite(cx, start + ((tk >> 10) & 31u), kc, sub_end(g.b0, g.b1, g.nsub, g.first + u, S));
                 store_rec(dst, r);
                 more = !(r.p == old.p && r.kc == old.kc) && (u + 1 < g.n);
-                tp = r.p;
-                packed = r.kc | (sw << 12) | ((u + 1) << 16);
+                task = pack_task(r.kc, r.p - (start + S), sw, u + 1);
             }
-            push_task(more, tp, packed, qout, &s_cnt[cn]);
+            push_task(more, task, s_queue, &s_cnt[cn]);
         }
         __syncthreads();
         ci = cn;
@@ -615,7 +620,7 @@ static size_t table_lds(const MjDeviceBatch &b, uint32_t waves) {
 hipError_t mj_launch_entropy(const MjDeviceBatch &b, hipStream_t s) {
     if (b.n_entropy_wg == 0) return hipSuccess;
     static const size_t pad = getenv("MJ_TUNE_LDS_PAD") ? (size_t) atol(getenv("MJ_TUNE_LDS_PAD")) : 0;   /* occupancy experiments */
-    const size_t lds = table_lds(b, 0) + SYNC_WAVES * sizeof(SeqGeo) + 4 * sizeof(uint32_t) + 2 * SYNC_TPB * sizeof(uint2) +
+    const size_t lds = table_lds(b, 0) + SYNC_WAVES * sizeof(SeqGeo) + 4 * sizeof(uint32_t) + SYNC_TPB * sizeof(uint32_t) +
                        (size_t) b.max_nac * sizeof(MjHuffRun) + pad;
     hipLaunchKernelGGL(mj_k_entropy_sync, dim3(b.n_entropy_wg), dim3(SYNC_TPB), lds, s, b);
     return hipGetLastError();
