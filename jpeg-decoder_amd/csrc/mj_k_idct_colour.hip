@@ -98,20 +98,22 @@ __device__ __forceinline__ void idct8(float &d0, float &d1, float &d2, float &d3
 /* dct.c:187-193 with CLAMP_8 (dct.c:6): clamp(0.25*x + 128) in double, then truncate.
  * q is 0.25*x already (see idct8<true>).  q + 128 is exact in double, and for a sum
  * that is not negative truncation is floor(q) + 128; a negative sum clamps to 0 either
- * way.  So the double arithmetic reduces, bit for bit, to a float floor, a clamp to
- * [-128, 127] (which also keeps the integer conversion in range) and an integer add. */
-__device__ __forceinline__ uint32_t finish(float q) {
-    const float f = fminf(fmaxf(floorf(q), -128.0f), 127.0f);
-    return (uint32_t) ((int32_t) f + 128);
+ * way.  floor(q) + 128 is an integer, exact in float wherever it is inside [0, 255], and
+ * the conversion instruction saturates to that range, so the double arithmetic reduces,
+ * bit for bit, to a floor, an add and a saturating conversion -- which also places the
+ * byte: the result is `word` with byte `pos` replaced by the sample. */
+__device__ __forceinline__ uint32_t finish(float q, uint32_t pos, uint32_t word) {
+    return __builtin_amdgcn_cvt_pk_u8_f32(floorf(q) + 128.0f, pos, word);
 }
 
 /* colour_conversion.c:76-79 as compiled by gcc 11.4 -O2: below zero -> 0, above
  * 256 -> 255, otherwise truncate through a 32-bit integer (so exactly 256.0f, which
- * one (Y,Cb,Cr) triple reaches in G, wraps to 0). */
-__device__ __forceinline__ uint32_t store8(float v) {
-    const int32_t i = (int32_t) v;
-    const uint32_t r = (uint32_t) min(max(i, 0), 255);
-    return (v == 256.0f) ? 0u : r;
+ * one (Y,Cb,Cr) triple reaches in G, wraps to 0).  Truncation of a value that is not
+ * negative is floor, and the conversion saturates; the result replaces byte `pos` of
+ * `word`. */
+__device__ __forceinline__ uint32_t store8(float v, uint32_t pos, uint32_t word) {
+    const uint32_t r = __builtin_amdgcn_cvt_pk_u8_f32(floorf(v), pos, word);
+    return (v == 256.0f) ? (word & ~(0xFFu << (8 * pos))) : r;
 }
 
 /* colour_conversion.c:71-74, per chroma sample value, from per-workgroup LDS tables:
@@ -140,7 +142,7 @@ __device__ __forceinline__ uint32_t ycc_to_rgb24(uint32_t Y, const ChromaRow tcb
     const uint32_t R = (uint32_t) min(max((int32_t) Y + tcr.o, 0), 255);
     const float G = (float) ((y - tcb.g) - tcr.g);
     const uint32_t B = (uint32_t) min(max((int32_t) Y + tcb.o, 0), 255);
-    return R | (store8(G) << 8) | (B << 16);
+    return store8(G, 1, R | (B << 16));
 }
 
 /* 12-byte store of four RGB24 pixels (4-byte aligned) */
@@ -328,8 +330,8 @@ __global__ __launch_bounds__(TPB, MJ_IDCT_WAVES) void mj_k_idct_colour(MjDeviceB
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             const float4 lo4 = *reinterpret_cast<const float4 *>(tr + r * 8), hi4 = *reinterpret_cast<const float4 *>(tr + r * 8 + 4);
-            const uint32_t lo = finish(lo4.x) | (finish(lo4.y) << 8) | (finish(lo4.z) << 16) | (finish(lo4.w) << 24);
-            const uint32_t hi = finish(hi4.x) | (finish(hi4.y) << 8) | (finish(hi4.z) << 16) | (finish(hi4.w) << 24);
+            const uint32_t lo = finish(lo4.w, 3, finish(lo4.z, 2, finish(lo4.y, 1, finish(lo4.x, 0, 0))));
+            const uint32_t hi = finish(hi4.w, 3, finish(hi4.z, 2, finish(hi4.y, 1, finish(hi4.x, 0, 0))));
             /* row r of the samples, over the block's own coefficients: all eight lanes
              * have read theirs by now */
             *reinterpret_cast<uint2 *>(bp + r * 8) = make_uint2(lo, hi);
