@@ -43,25 +43,54 @@ __constant__ uint8_t c_zzinv[64] = {0,  1,  5,  6,  14, 15, 27, 28, 2,  4,  7,  
                                     41, 43, 9,  11, 18, 24, 31, 40, 44, 53, 10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38,
                                     46, 51, 55, 60, 21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63};
 
-/* 8-point inverse butterfly (dct.c:296-341).  (float)(C * (double)x) is a product
- * rounded to double and then to float, as the C source's mixed types imply.
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+/* (float) (C * (double) x) -- a product with a double constant, rounded to double and
+ * then to float, as the C source's mixed types imply -- without leaving single
+ * precision: split C = hi + lo with hi = (float) C and lo = (float) (C - hi); then
+ * fma(hi, x, lo * x), two roundings of which the first is far below the result's last
+ * bit, gives the same float.  That is a property of the constant, checked for the two
+ * mantissas used here (0.707106781 and 1.414213562, and their multiples by powers of
+ * two) against the double computation for every one of the 2^23 float mantissas of x;
+ * signs and exponents do not matter, and (hi, lo) = (1, 0) leaves x as it is.  Two
+ * values at a time, it is two packed instructions instead of six conversions and
+ * multiplications. */
+struct SplitConst {
+    float hi, lo;
+};
+constexpr SplitConst split_const(double c) {
+    return SplitConst{(float) c, (float) (c - (double) (float) c)};
+}
+__device__ __forceinline__ float mulc(float x, SplitConst c) {
+    return __builtin_fmaf(c.hi, x, c.lo * x);
+}
+__device__ __forceinline__ f2 mulc(f2 x, SplitConst c) {
+    const f2 hi = {c.hi, c.hi}, lo = {c.lo, c.lo};
+    return __builtin_elementwise_fma(hi, x, lo * x);
+}
+
+/* 8-point inverse butterfly (dct.c:296-341).
  *
  * The reference halves after every add ("0.5 * (a + b)").  Multiplying by a power
  * of two is exact and commutes with every rounding, so the halvings are carried as
  * an implicit scale instead (capital letters = 2x or 4x the reference's variable)
- * and folded into the double constants: the results are bit-identical and twelve
- * multiplies per butterfly disappear. */
+ * and folded into the constants: the results are bit-identical and twelve
+ * multiplies per butterfly disappear.  Products of one value with one constant go
+ * through mulc; the two-term rotations keep the reference's double arithmetic. */
 template <bool FINAL>
 __device__ __forceinline__ void idct8(float &d0, float &d1, float &d2, float &d3, float &d4, float &d5, float &d6,
                                       float &d7) {
     /* FINAL: the caller's next step is 0.25 * x + 128 (dct.c:192); the exact factor
      * 0.25 is folded into the last constant as well */
-    constexpr double C = FINAL ? 0.25 * 0.707106781 : 0.707106781, C2 = 2.0 * 0.707106781;
-    const float t0 = (float) (1.414213562 * (double) d0);
+    constexpr SplitConst C = split_const(FINAL ? 0.25 * 0.707106781 : 0.707106781);
+    constexpr double C2 = 2.0 * 0.707106781;
+    static_assert(C2 == 1.414213562, "one split serves both constants");
+    constexpr SplitConst S2 = split_const(C2);
+    const float t0 = mulc(d0, S2);
     const float t1 = d4, t2 = d2, t3 = d6;
+    const f2 T56 = mulc((f2){d3, d5}, S2);               /* 2 t5, 2 t6 */
     const float T4 = d1 - d7;                            /* 2 t4 */
-    const float T5 = (float) (C2 * (double) d3);         /* 2 t5 */
-    const float T6 = (float) (C2 * (double) d5);         /* 2 t6 */
+    const float T5 = T56.x, T6 = T56.y;
     const float T7 = d1 + d7;                            /* 2 t7 */
 
     const float U0 = t0 + t1;                            /* 2 u0 */
@@ -85,14 +114,18 @@ __device__ __forceinline__ void idct8(float &d0, float &d1, float &d2, float &d3
     const float W7 = (float) (0.55557023302 * u4d + 0.8314696123 * u7d);
 
     /* reference: 1.414213562 * 2 * (w + w'); here the sum carries a factor 4 */
-    d0 = (float) (C * (double) (W0 + W7));
-    d1 = (float) (C * (double) (W1 + W6));
-    d2 = (float) (C * (double) (W2 + W5));
-    d3 = (float) (C * (double) (W3 + W4));
-    d4 = (float) (C * (double) (W3 - W4));
-    d5 = (float) (C * (double) (W2 - W5));
-    d6 = (float) (C * (double) (W1 - W6));
-    d7 = (float) (C * (double) (W0 - W7));
+    const f2 o07 = mulc((f2){W0, W0} + (f2){W7, -W7}, C);
+    const f2 o16 = mulc((f2){W1, W1} + (f2){W6, -W6}, C);
+    const f2 o25 = mulc((f2){W2, W2} + (f2){W5, -W5}, C);
+    const f2 o34 = mulc((f2){W3, W3} + (f2){W4, -W4}, C);
+    d0 = o07.x;
+    d1 = o16.x;
+    d2 = o25.x;
+    d3 = o34.x;
+    d4 = o34.y;
+    d5 = o25.y;
+    d6 = o16.y;
+    d7 = o07.y;
 }
 
 /* dct.c:187-193 with CLAMP_8 (dct.c:6): clamp(0.25*x + 128) in double, then truncate.
@@ -287,7 +320,8 @@ __global__ __launch_bounds__(TPB, MJ_IDCT_WAVES) void mj_k_idct_colour(MjDeviceB
         /* the reference scales the first row and the first column by 1/sqrt(2) before the
          * butterflies (dct.c:164-167), the corner twice: lane 0 scales its whole row, the
          * others multiply by one, which changes nothing */
-        const double row_scale = (r == 0) ? 0.707106781 : 1.0;
+        constexpr SplitConst RS = split_const(0.707106781);
+        const SplitConst row_scale = {(r == 0) ? RS.hi : 1.0f, (r == 0) ? RS.lo : 0.0f};
         for (uint32_t b0 = 0; b0 < nblk; b0 += TPB / 8) {
             const uint32_t blk = b0 + grp;
             if (blk >= nblk) continue;                       /* whole groups of eight lanes drop out together */
@@ -307,10 +341,12 @@ __global__ __launch_bounds__(TPB, MJ_IDCT_WAVES) void mj_k_idct_colour(MjDeviceB
                     c[j] = (float) (int16_t) (z * q);
                 }
             }
-            c[0] = (float) ((double) c[0] * 0.707106781);    /* first column */
+            c[0] = mulc(c[0], RS);                           /* first column */
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                c[j] = (float) ((double) c[j] * row_scale);  /* first row */
+            for (int j = 0; j < 8; j += 2) {                 /* first row */
+                const f2 v = mulc((f2){c[j], c[j + 1]}, row_scale);
+                c[j] = v.x;
+                c[j + 1] = v.y;
             }
             idct8<false>(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]);
             /* rows -> columns (the reference transposes, runs rows again, and transposes
