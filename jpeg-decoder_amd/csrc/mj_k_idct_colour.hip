@@ -206,7 +206,7 @@ __device__ __forceinline__ void store_quad(uint8_t *o, const uint32_t px[4], uin
 /* Where the samples of the tile live after the butterflies: block `blk` of the tile
  * keeps its 8x8 bytes, row-major, in the first 64 bytes of its LDS slot. */
 __device__ __forceinline__ uint32_t sample_off(uint32_t blk, uint32_t x, uint32_t y) {
-    return blk * COEF_STRIDE + (y & 7u) * 8u + (x & 7u);
+    return __umul24(blk, COEF_STRIDE) + (y & 7u) * 8u + (x & 7u);
 }
 
 /*
@@ -224,6 +224,7 @@ __device__ __forceinline__ void colour_fast(const uint8_t *s_smp, const ChromaRo
     constexpr int NC = 4 >> SH, ROWS = 1 << SV;
     const uint32_t quads = tile_w / 4, prow_n = tile_h >> SV;
     const uint32_t dy = TPB / quads, dq = TPB - dy * quads;
+    uint8_t *rgb_tile = rgb + (uint64_t) py0 * pitch;
     uint32_t pr = threadIdx.x / quads;
     uint32_t qx = threadIdx.x - pr * quads;
     for (; pr < prow_n; pr += dy, qx += dq) {
@@ -238,8 +239,9 @@ __device__ __forceinline__ void colour_fast(const uint8_t *s_smp, const ChromaRo
         /* chroma samples of the patch and their product rows: chroma pixel (x >> SH, pr)
          * of MCU x >> (3 + SH) */
         const uint32_t cx = x >> SH, mcu = x >> (3 + SH);
-        const uint8_t *cbp = s_smp + sample_off(mcu * bpm + s1, cx, pr);
-        const uint8_t *crp = s_smp + sample_off(mcu * bpm + s2, cx, pr);
+        const uint32_t mblk = __umul24(mcu, bpm);
+        const uint8_t *cbp = s_smp + sample_off(mblk + s1, cx, pr);
+        const uint8_t *crp = s_smp + sample_off(mblk + s2, cx, pr);
         uint32_t cbw, crw;
         if (SH == 0) {
             cbw = *reinterpret_cast<const uint32_t *>(cbp);
@@ -263,14 +265,16 @@ __device__ __forceinline__ void colour_fast(const uint8_t *s_smp, const ChromaRo
         for (int r = 0; r < ROWS; r++) {
             if (gy + r >= Y) break;
             const uint32_t ly = y + r;
-            const uint32_t lblk = mcu * bpm + s0 + ((ly >> 3) << SH) + lcol;
+            const uint32_t lblk = mblk + s0 + ((ly >> 3) << SH) + lcol;
             const uint32_t yw = *reinterpret_cast<const uint32_t *>(s_smp + sample_off(lblk, x, ly));
             uint32_t px[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 px[k] = ycc_to_rgb24((yw >> (8 * k)) & 0xFFu, tb[k >> SH], tr[k >> SH]);
             }
-            store_quad(rgb + (uint64_t) (gy + r) * pitch + 3 * gx, px, gx, X);
+            /* rows of one tile are at most a few megabytes apart: 32-bit offsets from the
+             * tile's first row */
+            store_quad(rgb_tile + (__umul24(y + r, pitch) + 3u * gx), px, gx, X);
         }
     }
 }
@@ -322,12 +326,14 @@ __global__ __launch_bounds__(TPB, MJ_IDCT_WAVES) void mj_k_idct_colour(MjDeviceB
          * others multiply by one, which changes nothing */
         constexpr SplitConst RS = split_const(0.707106781);
         const SplitConst row_scale = {(r == 0) ? RS.hi : 1.0f, (r == 0) ? RS.lo : 0.0f};
-        for (uint32_t b0 = 0; b0 < nblk; b0 += TPB / 8) {
+        uint32_t slot = grp % bpm;                           /* block slot inside the MCU, kept up incrementally */
+        const uint32_t slot_step = (TPB / 8) % bpm;
+        for (uint32_t b0 = 0; b0 < nblk; b0 += TPB / 8, slot += slot_step) {
             const uint32_t blk = b0 + grp;
             if (blk >= nblk) continue;                       /* whole groups of eight lanes drop out together */
-            const uint32_t slot = blk % bpm;
+            slot = (slot >= bpm) ? slot - bpm : slot;
             const uint32_t comp = im.blk_comp[slot];
-            uint8_t *bp = s_blk + blk * COEF_STRIDE;
+            uint8_t *bp = s_blk + __umul24(blk, COEF_STRIDE);
             float c[8];
             {
                 const uint4 qv = *reinterpret_cast<const uint4 *>(&s_qt[comp][8 * r]);
