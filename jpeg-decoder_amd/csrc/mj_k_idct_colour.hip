@@ -191,10 +191,13 @@ __device__ __forceinline__ void store_quad(uint8_t *o, const uint32_t px[4], uin
         v.c = (px[2] >> 16) | (px[3] << 8);
         *reinterpret_cast<Rgb4 *>(o) = v;
     } else {
-        for (uint32_t k = 0; k < 4 && gx + k < X; k++) {
-            o[3 * k] = (uint8_t) px[k];
-            o[3 * k + 1] = (uint8_t) (px[k] >> 8);
-            o[3 * k + 2] = (uint8_t) (px[k] >> 16);
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {      /* constant indices: px stays in registers */
+            if (gx + k < X) {
+                o[3 * k] = (uint8_t) px[k];
+                o[3 * k + 1] = (uint8_t) (px[k] >> 8);
+                o[3 * k + 2] = (uint8_t) (px[k] >> 16);
+            }
         }
     }
 }
@@ -213,68 +216,87 @@ __device__ __forceinline__ uint32_t sample_off(uint32_t blk, uint32_t x, uint32_
  * Colour stage for the common layouts: luma at full resolution, both chroma
  * components subsampled by 2^SH horizontally and 2^SV vertically with one block each
  * per MCU (4:4:4, 4:2:2, 4:2:0, 4:4:0, 4:1:1).  A thread converts a patch of
- * 4 x 2^SV pixels per step, so every chroma sample and its two table rows are fetched
- * once per patch.  s0, s1, s2: first block slot of each component inside the MCU.
+ * 8 x 2^SV pixels per step -- one row of a luma block per pixel row -- so every chroma
+ * sample and its two table rows are fetched once per patch and the address arithmetic
+ * is paid once per eight or sixteen pixels.  s0, s1, s2: first block slot of each
+ * component inside the MCU.
  */
 template <int SH, int SV>
 __device__ __forceinline__ void colour_fast(const uint8_t *s_smp, const ChromaRow *s_tcb, const ChromaRow *s_tcr, uint32_t bpm,
                                             uint32_t s0, uint32_t s1, uint32_t s2, uint32_t tile_w, uint32_t tile_h,
                                             uint32_t px0, uint32_t py0, uint32_t X, uint32_t Y, uint32_t pitch,
                                             uint8_t *rgb) {
-    constexpr int NC = 4 >> SH, ROWS = 1 << SV;
-    const uint32_t quads = tile_w / 4, prow_n = tile_h >> SV;
-    const uint32_t dy = TPB / quads, dq = TPB - dy * quads;
+    constexpr int NC = 8 >> SH, HC = 4 >> SH, ROWS = 1 << SV;   /* chroma samples per patch row, per half of it */
+    const uint32_t cols = tile_w / 8, prow_n = tile_h >> SV;
+    const uint32_t dy = TPB / cols, dq = TPB - dy * cols;
     uint8_t *rgb_tile = rgb + (uint64_t) py0 * pitch;
-    uint32_t pr = threadIdx.x / quads;
-    uint32_t qx = threadIdx.x - pr * quads;
+    uint32_t pr = threadIdx.x / cols;
+    uint32_t qx = threadIdx.x - pr * cols;
     for (; pr < prow_n; pr += dy, qx += dq) {
-        if (qx >= quads) {
-            qx -= quads;
+        if (qx >= cols) {
+            qx -= cols;
             pr++;
             if (pr >= prow_n) break;
         }
-        const uint32_t x = qx * 4, gx = px0 + x;
+        const uint32_t x = qx * 8, gx = px0 + x;
         const uint32_t y = pr << SV, gy = py0 + y;
         if (gy >= Y || gx >= X) continue;
-        /* chroma samples of the patch and their product rows: chroma pixel (x >> SH, pr)
-         * of MCU x >> (3 + SH) */
+        /* chroma samples of the patch: chroma pixels (x >> SH ...) of row pr of MCU x >> (3 + SH) */
         const uint32_t cx = x >> SH, mcu = x >> (3 + SH);
         const uint32_t mblk = __umul24(mcu, bpm);
         const uint8_t *cbp = s_smp + sample_off(mblk + s1, cx, pr);
         const uint8_t *crp = s_smp + sample_off(mblk + s2, cx, pr);
-        uint32_t cbw, crw;
-        if (SH == 0) {
-            cbw = *reinterpret_cast<const uint32_t *>(cbp);
-            crw = *reinterpret_cast<const uint32_t *>(crp);
-        } else if (SH == 1) {
-            cbw = *reinterpret_cast<const uint16_t *>(cbp);
-            crw = *reinterpret_cast<const uint16_t *>(crp);
+        uint32_t cbw[2] = {0, 0}, crw[2] = {0, 0};
+        if (NC == 8) {
+            const uint2 vb = *reinterpret_cast<const uint2 *>(cbp), vr = *reinterpret_cast<const uint2 *>(crp);
+            cbw[0] = vb.x;
+            cbw[1] = vb.y;
+            crw[0] = vr.x;
+            crw[1] = vr.y;
+        } else if (NC == 4) {
+            const uint32_t vb = *reinterpret_cast<const uint32_t *>(cbp), vr = *reinterpret_cast<const uint32_t *>(crp);
+            cbw[0] = vb & 0xFFFFu;
+            cbw[1] = vb >> 16;
+            crw[0] = vr & 0xFFFFu;
+            crw[1] = vr >> 16;
         } else {
-            cbw = *cbp;
-            crw = *crp;
-        }
-        ChromaRow tb[NC], tr[NC];
-#pragma unroll
-        for (int i = 0; i < NC; i++) {
-            tb[i] = s_tcb[(cbw >> (8 * i)) & 0xFFu];
-            tr[i] = s_tcr[(crw >> (8 * i)) & 0xFFu];
+            const uint32_t vb = *reinterpret_cast<const uint16_t *>(cbp), vr = *reinterpret_cast<const uint16_t *>(crp);
+            cbw[0] = vb & 0xFFu;
+            cbw[1] = vb >> 8;
+            crw[0] = vr & 0xFFu;
+            crw[1] = vr >> 8;
         }
         /* luma block: column (x >> 3) & (2^SH - 1), row r >> 3 of the MCU's luma blocks */
         const uint32_t lcol = (x >> 3) & ((1u << SH) - 1u);
+        uint2 yw[ROWS];
 #pragma unroll
         for (int r = 0; r < ROWS; r++) {
-            if (gy + r >= Y) break;
             const uint32_t ly = y + r;
             const uint32_t lblk = mblk + s0 + ((ly >> 3) << SH) + lcol;
-            const uint32_t yw = *reinterpret_cast<const uint32_t *>(s_smp + sample_off(lblk, x, ly));
-            uint32_t px[4];
+            yw[r] = *reinterpret_cast<const uint2 *>(s_smp + sample_off(lblk, 0, ly));
+        }
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                px[k] = ycc_to_rgb24((yw >> (8 * k)) & 0xFFu, tb[k >> SH], tr[k >> SH]);
+        for (int h = 0; h < 2; h++) {                   /* four pixels of every row at a time */
+            if (gx + 4 * h >= X) break;
+            ChromaRow tb[HC], tr[HC];
+#pragma unroll
+            for (int i = 0; i < HC; i++) {
+                tb[i] = s_tcb[(cbw[h] >> (8 * i)) & 0xFFu];
+                tr[i] = s_tcr[(crw[h] >> (8 * i)) & 0xFFu];
             }
-            /* rows of one tile are at most a few megabytes apart: 32-bit offsets from the
-             * tile's first row */
-            store_quad(rgb_tile + (__umul24(y + r, pitch) + 3u * gx), px, gx, X);
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) {
+                if (gy + r >= Y) break;
+                const uint32_t w = h ? yw[r].y : yw[r].x;
+                uint32_t px[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    px[k] = ycc_to_rgb24((w >> (8 * k)) & 0xFFu, tb[k >> SH], tr[k >> SH]);
+                }
+                /* rows of one tile are at most a few megabytes apart: 32-bit offsets from the
+                 * tile's first row */
+                store_quad(rgb_tile + (__umul24(y + r, pitch) + 3u * (gx + 4 * h)), px, gx + 4 * h, X);
+            }
         }
     }
 }
