@@ -5,6 +5,7 @@ library or a HIP device is missing, construction raises.
 """
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -99,6 +100,7 @@ class Context:
     def __init__(self, device=0):
         self.lib = load_library()
         self.h = C.c_void_p()
+        self._batches = weakref.WeakSet()      # a batch must not outlive its context
         _check(self.lib, self.lib.mj_create(device, C.byref(self.h)), "mj_create")
 
     def set_stream(self, hip_stream_ptr):
@@ -109,6 +111,8 @@ class Context:
 
     def close(self):
         if self.h:
+            for b in list(self._batches):
+                b.close()
             self.lib.mj_destroy(self.h)
             self.h = C.c_void_p()
 
@@ -132,6 +136,7 @@ class Batch:
         _check(self.lib, self.lib.mj_batch_create(ctx.h, bufs, lens, n, flags, C.byref(self.h)), "mj_batch_create")
         self.n = n
         self.flags = flags
+        ctx._batches.add(self)
 
     def decode(self):
         _check(self.lib, self.lib.mj_batch_decode(self.h), "mj_batch_decode")

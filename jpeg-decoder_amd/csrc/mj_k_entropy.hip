@@ -596,18 +596,21 @@ __global__ __launch_bounds__(TPB) void mj_k_entropy_serial(MjDeviceBatch b) {
         uint32_t blk = iv * im.ri * im.bpm;
         const uint32_t blk_end = min(blk + im.ri * im.bpm, n_blocks);
         const uint32_t p0 = ivl[iv] * 8u, end = ivl[iv + 1] * 8u;
-        if (p0 >= end) continue;
-        MjLane L;
-        mj_lane_init(cx, L, p0, 0, 0);
-        MjAccReg acc = {0, 0, 0, 0};
-        while (L.p < end && blk < blk_end) {
-            mj_checkpoint(cx, L);
-            mj_refill(L);
-            const uint32_t at = blk;
-            const MjSym s = mj_step<true>(cx, L, acc, blk, 0);
-            if (s.store) cx.coefs[(uint64_t) at * 64 + s.kpos] = (int16_t) s.val;
-            if (s.store2) cx.coefs[(uint64_t) at * 64 + s.kpos2] = (int16_t) s.val2;
+        if (p0 < end) {
+            MjLane L;
+            mj_lane_init(cx, L, p0, 0, 0);
+            MjAccReg acc = {0, 0, 0, 0};
+            while (L.p < end && blk < blk_end) {
+                mj_checkpoint(cx, L);
+                mj_refill(L);
+                const uint32_t at = blk;
+                const MjSym s = mj_step<true>(cx, L, acc, blk, 0);
+                if (s.store) cx.coefs[(uint64_t) at * 64 + s.kpos] = (int16_t) s.val;
+                if (s.store2) cx.coefs[(uint64_t) at * 64 + s.kpos2] = (int16_t) s.val2;
+            }
         }
+        /* the stream ended before the interval's blocks did */
+        if (blk < blk_end) atomicOr(&b.dyn[ii].status, 1u);
     }
 }
 

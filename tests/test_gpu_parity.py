@@ -215,3 +215,69 @@ def test_dropin_api_like_the_reference_viewer(ctx, name):
     lib.free_img(img)
     lib.free_frame_header.argtypes = [C.POINTER(_FrameHeader)]
     lib.free_frame_header(C.byref(fh))
+
+
+def _entropy_start(data):
+    i = data.index(b"\xff\xda")
+    return i + 2 + ((data[i + 2] << 8) | data[i + 3])
+
+
+def _damaged_variants(data, seed):
+    """Truncations, bit flips, stray FF bytes and an extra RSTn inside the entropy-coded
+    segment: what a decoder meets on a cut-off transfer or a bad sector."""
+    rng = np.random.default_rng(seed)
+    h = _entropy_start(data)
+    n = len(data) - h
+    out = []
+    for frac in (0.0, 0.3, 0.8):
+        out.append(("truncated", data[:h + int(n * frac)]))
+    for _ in range(4):
+        d = bytearray(data)
+        for _ in range(int(rng.integers(1, 5))):
+            d[h + int(rng.integers(0, n - 2))] ^= 1 << int(rng.integers(0, 8))
+        out.append(("bitflips", bytes(d)))
+    d = bytearray(data)
+    for _ in range(3):
+        d[h + int(rng.integers(0, n - 2))] = 0xFF
+    out.append(("stray_ff", bytes(d)))
+    d = bytearray(data)
+    p = h + int(rng.integers(0, n - 4))
+    d[p], d[p + 1] = 0xFF, 0xD0 + int(rng.integers(0, 8))
+    out.append(("extra_rst", bytes(d)))
+    return out
+
+
+@pytest.mark.parametrize("flags", [0, binding.MJ_ENTROPY_SERIAL])
+def test_damaged_streams_neither_fault_nor_disturb_their_neighbours(ctx, flags):
+    """The reference reads past the end of a damaged file (decode.c:578-589 has no bound);
+    there is nothing to be equal to.  The contract here: every access stays inside the
+    batch's buffers, a stream that ends early is reported in the image's status word, and
+    the intact images of the same batch are decoded exactly as if they were alone."""
+    names = ["c420_q85_100x75_ri3", "c444_q85_80x56_rirow", "g_q75_72x40_ri4", "c422_q95_opt_136x40_ri5"]
+    files, expect = [], []
+    for k, name in enumerate(names):
+        d, g = load_fixture(name)
+        files.append(d)
+        expect.append(g)
+        for kind, bad in _damaged_variants(d, 100 + k):
+            files.append(bad)
+            expect.append(kind)
+    d, g = load_fixture("C1_c420_q85_512x512")
+    for kind, bad in _damaged_variants(d, 7)[:5]:
+        files.append(bad)
+        expect.append(kind)
+    files.append(d)
+    expect.append(g)
+    b = ctx.batch(files, flags)
+    for _ in range(2):
+        b.decode()
+        b.sync()
+        for i, e in enumerate(expect):
+            if isinstance(e, str):
+                st = b.status(i)
+                if e == "truncated":
+                    assert st != 0, f"image {i}: a stream cut short must be reported"
+                b.rgb(i)    # readable, whatever it holds
+            else:
+                _check_image(b, i, e["coefs"], None, e["rgb"], f"intact image {i}")
+    b.close()
