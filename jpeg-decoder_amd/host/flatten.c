@@ -20,6 +20,14 @@ static int fail(const char **why, const char *msg) {
     return -1;
 }
 
+void mj_parsed_free(MjParsed *p);
+
+/* a rejected file leaves nothing allocated behind */
+static int fail_free(MjParsed *out, const char **why, const char *msg) {
+    mj_parsed_free(out);
+    return fail(why, msg);
+}
+
 int mj_parse_headers(const uint8_t *buf, size_t len, MjParsed *out, const char **why) {
     memset(out, 0, sizeof *out);
     out->fh.process = (Encoding) -1; /* jpeg_decoder.c:54 */
@@ -41,12 +49,12 @@ int mj_parse_headers(const uint8_t *buf, size_t len, MjParsed *out, const char *
             break;
         }
         if (bs.encoded_data + 2 > end) {
-            return fail(why, "truncated segment header");
+            return fail_free(out, why, "truncated segment header");
         }
         size_t seglen = ((size_t) bs.encoded_data[0] << 8) | bs.encoded_data[1];
         uint8_t *seg = bs.encoded_data;
         if (seglen < 2 || seg + seglen > end) {
-            return fail(why, "segment length runs past the end of the file");
+            return fail_free(out, why, "segment length runs past the end of the file");
         }
         switch (m) {
             case 0xC0: /* SOF0 baseline */
@@ -55,31 +63,31 @@ int mj_parse_headers(const uint8_t *buf, size_t len, MjParsed *out, const char *
                     free_frame_header(&out->fh);
                 }
                 if (decode_frame_header(m == 0xC0 ? BDCT : ESDCTHC, &bs, &out->fh) != 0) {
-                    return fail(why, "bad frame header");
+                    return fail_free(out, why, "bad frame header");
                 }
                 out->have_fh = 1;
                 break;
             case 0xC2: case 0xC3: case 0xC5: case 0xC6: case 0xC7: case 0xC9: case 0xCA: case 0xCB:
             case 0xCD: case 0xCE: case 0xCF:
-                return fail(why, "not a baseline sequential Huffman JPEG (progressive/lossless/arithmetic)");
+                return fail_free(out, why, "not a baseline sequential Huffman JPEG (progressive/lossless/arithmetic)");
             case 0xC4:
                 if (!out->have_hts) {
                     new_huff_tables(out->fh.process, &out->hts); /* decode.c:273-279 */
                     out->have_hts = 1;
                 }
                 if (decode_huff_tables(&bs, &out->hts) != 0) {
-                    return fail(why, "bad Huffman table segment");
+                    return fail_free(out, why, "bad Huffman table segment");
                 }
                 break;
             case 0xDB:
                 if (decode_quant_table(&bs, &out->qts) != 0) {
-                    return fail(why, "bad quantisation table segment");
+                    return fail_free(out, why, "bad quantisation table segment");
                 }
                 out->have_qts = 1;
                 break;
             case 0xDD:
                 if (decode_restart_interval(&bs, &out->ri) != 0) {
-                    return fail(why, "bad restart interval segment");
+                    return fail_free(out, why, "bad restart interval segment");
                 }
                 break;
             case 0xDC:
@@ -89,16 +97,16 @@ int mj_parse_headers(const uint8_t *buf, size_t len, MjParsed *out, const char *
                 break;
             case 0xDA:
                 if (!out->have_fh) {
-                    return fail(why, "scan before frame header");
+                    return fail_free(out, why, "scan before frame header");
                 }
                 if (!out->have_qts) {
-                    return fail(why, "scan without a quantisation table"); /* decode.c:321-326 */
+                    return fail_free(out, why, "scan without a quantisation table"); /* decode.c:321-326 */
                 }
                 if (!out->have_hts) {
-                    return fail(why, "scan without a Huffman table");
+                    return fail_free(out, why, "scan without a Huffman table");
                 }
                 if (decode_scan_header(&bs, &out->sh) != 0) {
-                    return fail(why, "bad scan header");
+                    return fail_free(out, why, "bad scan header");
                 }
                 out->ent_pos = (size_t) (seg + seglen - buf);
                 return 0;
@@ -108,7 +116,7 @@ int mj_parse_headers(const uint8_t *buf, size_t len, MjParsed *out, const char *
         bs.encoded_data = seg + seglen;
         bs.offset = 0;
     }
-    return fail(why, "no scan found");
+    return fail_free(out, why, "no scan found");
 }
 
 void mj_parsed_free(MjParsed *p) {

@@ -122,3 +122,37 @@ def test_sixteen_byte_classifier_equals_the_byte_rule():
                     nxt = int(buf[j + 1]) if j + 1 < n else 0
                     want = lib.mj_emu_classify(prev, int(buf[j]), nxt)
                 assert want == out[i], (n, j, hex(int(buf[j])))
+
+
+def test_damaged_headers_and_streams_are_rejected_or_decoded_never_crash():
+    """Random damage to the marker segments and to the entropy-coded data, through the host
+    parser and the host emulation of the kernels' algorithm: every call returns (the same
+    loop runs clean under AddressSanitizer and UBSan when the sources are built with
+    them)."""
+    emu = binding.Emu()
+    rng = np.random.default_rng(11)
+    done = rejected = 0
+    for name in ["c420_q85_100x75_ri3", "g_q75_72x40_ri4", "c444_q90_dqt16_56x40"]:
+        good, _ = load_fixture(name)
+        sos = good.index(b"\xff\xda")
+        hdr = sos + 2 + ((good[sos + 2] << 8) | good[sos + 3])
+        for v in range(150):
+            d = bytearray(good)
+            kind = v % 5
+            if kind == 0:
+                d[2 + int(rng.integers(0, hdr - 2))] = int(rng.integers(0, 256))
+            elif kind == 1:
+                d = d[:2 + int(rng.integers(0, hdr))]
+            elif kind == 2:
+                p = 2 + int(rng.integers(0, hdr - 4))
+                d[p], d[p + 1] = 0xFF, 0xC0 + int(rng.integers(0, 0x3F))
+            elif kind == 3:
+                d = d[:hdr + int(rng.integers(0, len(good) - hdr))]
+            else:
+                d[hdr + int(rng.integers(0, len(good) - hdr - 2))] ^= 1 << int(rng.integers(0, 8))
+            try:
+                emu.decode_coefs(bytes(d), 4096)
+                done += 1
+            except RuntimeError:
+                rejected += 1
+    assert done + rejected == 450 and done > 0 and rejected > 0
