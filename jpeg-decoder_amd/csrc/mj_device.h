@@ -155,7 +155,7 @@ typedef struct {
 typedef struct {
     MjState exit;
     uint32_t nb;          /* blocks completed */
-    int32_t dcsum[MJ_MAX_COMP]; /* sum of DC differences decoded, per component */
+    int32_t dcsum[MJ_MAX_COMP]; /* sum of DC differences decoded, per component, modulo 2^16 */
     uint32_t pad_;
 } MjSubRec;               /* 32 bytes */
 

@@ -259,6 +259,33 @@ struct MjAccReg {
     }
 };
 
+/* The same sums modulo 2^16, two to a register: what the counting passes keep.  A
+ * predictor is only ever used through the int16 it is stored as (decode.c:687-690), so
+ * every sum that feeds it may be taken modulo 2^16, and with two independent 16-bit
+ * fields per word adding to one component is a shift and a packed add instead of a
+ * four-way choice.  add() does not give the sum back. */
+struct MjAccPk {
+    uint32_t a01, a23;
+    MJ_HDM static uint32_t add16x2(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(uint32_t, __builtin_bit_cast(us2, a) + __builtin_bit_cast(us2, b));
+#else
+        return ((a + b) & 0xFFFFu) | (((a >> 16) + (b >> 16)) << 16);
+#endif
+    }
+    MJ_HDM int32_t add(uint32_t comp, int32_t v) {
+        const uint32_t field = ((uint32_t) v & 0xFFFFu) << ((comp & 1u) << 4);
+        const bool upper = (comp & 2u) != 0;
+        a01 = add16x2(a01, upper ? 0u : field);
+        a23 = add16x2(a23, upper ? field : 0u);
+        return 0;
+    }
+    MJ_HDM int32_t sum(uint32_t comp) const {        /* modulo 2^16, as a non-negative number */
+        return (int32_t) ((((comp & 2u) ? a23 : a01) >> ((comp & 1u) << 4)) & 0xFFFFu);
+    }
+};
+
 /* What one symbol did. */
 struct MjSym {
     int32_t val;      /* WRITE only: the coefficient value (for DC: the predictor after the addition) */

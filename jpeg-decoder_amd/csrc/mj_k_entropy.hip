@@ -121,16 +121,16 @@ struct LaneRec {      /* what a lane knows about one subsequence */
 /* Decode with an initialised lane up to `end`, counting blocks and DC differences */
 __device__ __forceinline__ LaneRec run_nowrite(const MjScanCtx &cx, MjLane &L, uint32_t end) {
     uint32_t nb = 0;
-    MjAccReg acc = {0, 0, 0, 0};
+    MjAccPk acc = {0, 0};
     mj_run_span(cx, L, end, nb, acc);
     LaneRec r;
     r.p = L.p;
     r.kc = (L.c << 8) | L.k;
     r.nb = nb;
-    r.d0 = acc.d0;
-    r.d1 = acc.d1;
-    r.d2 = acc.d2;
-    r.d3 = acc.d3;
+    r.d0 = acc.sum(0);       /* modulo 2^16: all a predictor needs */
+    r.d1 = acc.sum(1);
+    r.d2 = acc.sum(2);
+    r.d3 = acc.sum(3);
     return r;
 }
 
