@@ -249,7 +249,7 @@ int64_t mj_emu_decode_coefs(const uint8_t *file, size_t len, int16_t *coefs, int
             const uint32_t jl = (j + G < nsub) ? j + G - 1 : nsub - 1;   // the lane's last subsequence
             uint32_t p = j ? rec[j - 1].p : b0, k = j ? rec[j - 1].k : 0, c = j ? rec[j - 1].c : 0;
             uint32_t blk = blk0;
-            MjAccReg d = {pred[0], pred[1], pred[2], pred[3]};
+            MjAccPk d = MjAccPk::of(pred[0], pred[1], pred[2], pred[3]);
             bool skip = (k != 0);
             int16_t buf[64];
             memset(buf, 0, sizeof buf);

@@ -246,26 +246,17 @@ struct MjAccMem {
     }
 };
 
-struct MjAccReg {
-    int32_t d0, d1, d2, d3;
-    MJ_HDM int32_t add(uint32_t comp, int32_t v) {
-        const int32_t lo = (comp & 1u) ? d1 : d0, hi = (comp & 1u) ? d3 : d2;
-        const int32_t sum = ((comp & 2u) ? hi : lo) + v;
-        d0 = (comp == 0) ? sum : d0;
-        d1 = (comp == 1) ? sum : d1;
-        d2 = (comp == 2) ? sum : d2;
-        d3 = (comp == 3) ? sum : d3;
-        return sum;
-    }
-};
 
-/* The same sums modulo 2^16, two to a register: what the counting passes keep.  A
- * predictor is only ever used through the int16 it is stored as (decode.c:687-690), so
- * every sum that feeds it may be taken modulo 2^16, and with two independent 16-bit
- * fields per word adding to one component is a shift and a packed add instead of a
- * four-way choice.  add() does not give the sum back. */
+/* The sums in registers, modulo 2^16, two to a word.  A predictor is only ever used
+ * through the int16 it is stored as (decode.c:687-690), so every sum that feeds it may be
+ * taken modulo 2^16, and with two independent 16-bit fields per word adding to one
+ * component is a shift and a packed add instead of a four-way choice. */
 struct MjAccPk {
     uint32_t a01, a23;
+    MJ_HDM static MjAccPk of(int32_t d0, int32_t d1, int32_t d2, int32_t d3) {
+        const MjAccPk a = {((uint32_t) d0 & 0xFFFFu) | ((uint32_t) d1 << 16), ((uint32_t) d2 & 0xFFFFu) | ((uint32_t) d3 << 16)};
+        return a;
+    }
     MJ_HDM static uint32_t add16x2(uint32_t a, uint32_t b) {
 #if defined(__HIP_DEVICE_COMPILE__)
         typedef unsigned short us2 __attribute__((ext_vector_type(2)));
@@ -274,12 +265,15 @@ struct MjAccPk {
         return ((a + b) & 0xFFFFu) | (((a >> 16) + (b >> 16)) << 16);
 #endif
     }
+    /* adds v to the component's sum; returns the new sum, right in its low 16 bits */
     MJ_HDM int32_t add(uint32_t comp, int32_t v) {
-        const uint32_t field = ((uint32_t) v & 0xFFFFu) << ((comp & 1u) << 4);
+        const uint32_t sh = (comp & 1u) << 4;
         const bool upper = (comp & 2u) != 0;
+        const int32_t sum = (int32_t) ((upper ? a23 : a01) >> sh) + v;
+        const uint32_t field = ((uint32_t) v & 0xFFFFu) << sh;
         a01 = add16x2(a01, upper ? 0u : field);
         a23 = add16x2(a23, upper ? field : 0u);
-        return 0;
+        return sum;
     }
     MJ_HDM int32_t sum(uint32_t comp) const {        /* modulo 2^16, as a non-negative number */
         return (int32_t) ((((comp & 2u) ? a23 : a01) >> ((comp & 1u) << 4)) & 0xFFFFu);
@@ -398,7 +392,7 @@ MJ_HD MjSym mj_step(const MjScanCtx &cx, MjLane &L, ACC &acc, uint32_t &nb, uint
 /*
  * Decode symbols with an initialised lane until its position reaches `end`, counting
  * only: nb is advanced by the number of blocks completed and every DC difference is
- * added to its component's accumulator (MjAccMem or MjAccReg).  The lane can go on to
+ * added to its component's accumulator (MjAccMem or MjAccPk).  The lane can go on to
  * the next span as it is.
  */
 template <class ACC>
@@ -445,7 +439,7 @@ MJ_HD void mj_decode_span(const MjScanCtx &cx, uint32_t &p, uint32_t &k, uint32_
  * must point at the second-symbol tables (MjHuffSet.next).  The caller
  * runs mj_checkpoint at least every MJ_CHECK_EVERY steps.
  */
-MJ_HD void mj_write_step(const MjScanCtx &cx, MjLane &L, bool &skip, uint32_t &blk, uint32_t blk_end, MjAccReg &acc,
+MJ_HD void mj_write_step(const MjScanCtx &cx, MjLane &L, bool &skip, uint32_t &blk, uint32_t blk_end, MjAccPk &acc,
                          int16_t *blkbuf, bool &fin, uint32_t &fin_blk) {
     mj_refill(L);
     uint32_t ended = 0;

@@ -532,7 +532,7 @@ __global__ __launch_bounds__(TPB) void mj_k_entropy_write(MjDeviceBatch b) {
 
     uint32_t k = kc & 0xFFu, c = kc >> 8;
     uint32_t blk = se.blk + nb;
-    MjAccReg acc = {d0 + se.pred[0], d1 + se.pred[1], d2 + se.pred[2], d3 + se.pred[3]};
+    MjAccPk acc = MjAccPk::of(d0 + se.pred[0], d1 + se.pred[1], d2 + se.pred[2], d3 + se.pred[3]);
     bool skip = (k != 0);
     const uint32_t end = sub_end(g.b0, g.b1, g.nsub, first + u0 + (cnt ? cnt - 1 : 0), S);
     int16_t *blkbuf = reinterpret_cast<int16_t *>(s_blk + (wave * 64 + lane) * BLK_STRIDE);
@@ -599,7 +599,7 @@ __global__ __launch_bounds__(TPB) void mj_k_entropy_serial(MjDeviceBatch b) {
         if (p0 < end) {
             MjLane L;
             mj_lane_init(cx, L, p0, 0, 0);
-            MjAccReg acc = {0, 0, 0, 0};
+            MjAccPk acc = {0, 0};
             while (L.p < end && blk < blk_end) {
                 mj_checkpoint(cx, L);
                 mj_refill(L);
