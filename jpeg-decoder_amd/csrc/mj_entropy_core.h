@@ -84,11 +84,14 @@ MJ_HD uint32_t mj_mul24(uint32_t a, uint32_t b) {
     return a * b;
 #endif
 }
+static_assert(sizeof(MjHuffDev) == 3072, "table offsets below are index * 3 * 1024, by shifts");
 MJ_HD uint32_t mj_slot_tdc(uint32_t slot) {   /* byte offset of the slot's DC table */
-    return mj_mul24((slot >> 2) & 7u, (uint32_t) sizeof(MjHuffDev));
+    const uint32_t k = (slot & 0x1Cu) << 8;   /* index * 1024 */
+    return k + (k << 1);
 }
 MJ_HD uint32_t mj_slot_tac(uint32_t slot) {
-    return mj_mul24(slot >> 5, (uint32_t) sizeof(MjHuffDev));
+    const uint32_t k = (slot & 0xE0u) << 5;
+    return k + (k << 1);
 }
 
 MJ_HD uint32_t mj_be32(uint32_t v) {
