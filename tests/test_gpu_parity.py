@@ -281,3 +281,46 @@ def test_damaged_streams_neither_fault_nor_disturb_their_neighbours(ctx, flags):
             else:
                 _check_image(b, i, e["coefs"], None, e["rgb"], f"intact image {i}")
     b.close()
+
+
+TINY_AND_THIN = [
+    # (w, h, sampling, quality, restart interval, grey): the smallest images, single rows and
+    # columns of MCUs, and the widest and tallest an MCU row / column can get
+    (1, 1, "4:2:0", 85, 0, False),
+    (8, 1, None, 85, 0, True),
+    (7, 9, "4:4:4", 90, 0, False),
+    (8, 8, "4:2:2", 75, 1, False),
+    (17, 1, "4:2:0", 85, 0, False),
+    (1, 17, "4:4:0", 85, 1, False),
+    (16, 16, "4:1:1", 60, 0, False),
+    (65535, 8, "4:2:0", 70, 512, False),
+    (9, 65535 // 8, "4:2:2", 70, 0, False),
+    (65528, 3, None, 85, 0, True),
+]
+
+
+@pytest.mark.parametrize("case", TINY_AND_THIN, ids=lambda c: f"{c[0]}x{c[1]}_{c[2]}_ri{c[4]}")
+def test_tiny_and_extreme_shapes_vs_oracle(ctx, oracle, case):
+    w, h, samp, q, ri, grey = case
+    assert not (grey and w % 8), "grey widths that are not multiples of 8 hit the reference's stride quirk (colour_conversion.c:20)"
+    img = J.synth.synth_image(w, h, seed=w + 3 * h, grey=grey)
+    data = J.synth.encode_jpeg(img, samp or "4:4:4", q, ri)
+    o = oracle.decode(data)
+    b = ctx.batch([data], binding.MJ_WANT_PLANES)
+    b.decode()
+    _check_image(b, 0, o.coefs, o.planes, o.rgb, str(case))
+    b.close()
+
+
+def test_empty_and_unparsable_inputs_are_refused(ctx):
+    """No images, an empty buffer, bytes that are not a JPEG, and a progressive file: the
+    batch is refused with an error (decode_jpeg_buffer returns -1 for these, decode.c:138-424),
+    and the context stays usable."""
+    good, g = load_fixture("c420_q85_64x48")
+    for files in ([], [b""], [b"\x00" * 100], [good, b"\xff\xd8\xff\xd9"], [good.replace(b"\xff\xc0", b"\xff\xc2", 1)]):
+        with pytest.raises(RuntimeError):
+            ctx.batch(files, 0)
+    b = ctx.batch([good], 0)
+    b.decode()
+    _check_image(b, 0, g["coefs"], None, g["rgb"], "after refusals")
+    b.close()
