@@ -37,6 +37,7 @@ typedef struct mj_batch mj_batch;
 #define MJ_WANT_PLANES 0x1u   /* also store the padded u8 component planes (Image.buf) */
 #define MJ_TIMING      0x2u   /* bracket every kernel with HIP events on the batch stream */
 #define MJ_ENTROPY_SERIAL 0x4u /* diagnostic: one lane per restart interval, no subsequence sync */
+#define MJ_OUT_RGBA    0x8u   /* pixels leave as R, G, B, 255 (four bytes) instead of RGB24; rgb_pitch = 4 * X */
 
 typedef struct {
     int32_t X, Y;            /* frame size in pixels */
@@ -108,7 +109,7 @@ int mj_batch_status(mj_batch *b, int i, uint32_t *status);
 int mj_batch_scan_end(mj_batch *b, int i, size_t *offset);
 
 /* Device pointers (valid until mj_batch_destroy). */
-void *mj_batch_device_rgb(const mj_batch *b);    /* uint8, image i at rgb_offset, rows of rgb_pitch */
+void *mj_batch_device_rgb(const mj_batch *b);    /* uint8, image i at rgb_offset, rows of rgb_pitch; 3 bytes per pixel, 4 with MJ_OUT_RGBA */
 void *mj_batch_device_coefs(const mj_batch *b);  /* int16[64] per block, zigzag order, scan order */
 
 /* Synchronous device-to-host copies for checking results. */

@@ -16,6 +16,7 @@ EMU_PATH = os.path.join(_HERE, "libmjemu.so")
 MJ_WANT_PLANES = 0x1
 MJ_TIMING = 0x2
 MJ_ENTROPY_SERIAL = 0x4
+MJ_OUT_RGBA = 0x8
 T_SCAN, T_ENTROPY, T_ENTROPY_FIX, T_IDCT_COLOUR, T_MEMSET, T_COUNT = 0, 1, 2, 3, 4, 5
 KERNEL_NAMES = ["scan", "entropy", "entropy_fix", "idct_colour", "memset"]
 
@@ -156,8 +157,9 @@ class Batch:
 
     def rgb(self, i):
         inf = self.info(i)
-        out = np.empty((inf.Y, inf.X, 3), np.uint8)
-        _check(self.lib, self.lib.mj_batch_copy_rgb(self.h, i, out.ctypes.data, 3 * inf.X), "mj_batch_copy_rgb")
+        bpp = 4 if self.flags & MJ_OUT_RGBA else 3
+        out = np.empty((inf.Y, inf.X, bpp), np.uint8)
+        _check(self.lib, self.lib.mj_batch_copy_rgb(self.h, i, out.ctypes.data, bpp * inf.X), "mj_batch_copy_rgb")
         return out
 
     def coefs(self, i):

@@ -251,6 +251,7 @@ static int batch_build(mj_ctx *ctx, std::vector<MjPrepared> &prep, uint32_t flag
         cmp_total = align_up(cmp_total + im.raw_len + MJ_STREAM_PAD, 16);
         im.coef_off = coef_blocks;
         coef_blocks += (uint64_t) im.n_mcu * im.bpm;
+        if (flags & MJ_OUT_RGBA) im.pitch = 4 * im.X;
         im.rgb_off = rgb_total;
         rgb_total = align_up(rgb_total + (uint64_t) im.pitch * im.Y, 256);
         for (uint32_t c = 0; c < im.ncs; c++) {
@@ -316,6 +317,7 @@ static int batch_build(mj_ctx *ctx, std::vector<MjPrepared> &prep, uint32_t flag
     d.n_multi_cap = (uint32_t) n_multi;
     d.n_idct_wg = (uint32_t) n_idct;
     d.want_planes = (flags & MJ_WANT_PLANES) ? 1u : 0u;
+    d.rgba = (flags & MJ_OUT_RGBA) ? 1u : 0u;
     d.dbg = (flags >> 16) & 0xFFFFu;
     d.max_ntab = 1;
     d.max_nac = 1;
@@ -460,9 +462,10 @@ void *mj_batch_device_coefs(const mj_batch *b) {
 int mj_batch_copy_rgb(mj_batch *b, int i, uint8_t *dst, size_t dst_pitch) {
     if (!b || !dst || i < 0 || i >= (int) b->img.size()) return set_err("mj_batch_copy_rgb: bad arguments");
     const MjImageDev &im = b->img[i];
-    if (dst_pitch < (size_t) 3 * im.X) return set_err("mj_batch_copy_rgb: pitch smaller than a row");
+    const size_t row = (size_t) (b->d.rgba ? 4 : 3) * im.X;
+    if (dst_pitch < row) return set_err("mj_batch_copy_rgb: pitch smaller than a row");
     if (mj_batch_sync(b)) return -1;
-    HIP_TRY(hipMemcpy2D(dst, dst_pitch, b->d.rgb + im.rgb_off, im.pitch, (size_t) 3 * im.X, im.Y, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy2D(dst, dst_pitch, b->d.rgb + im.rgb_off, im.pitch, row, im.Y, hipMemcpyDeviceToHost));
     return 0;
 }
 

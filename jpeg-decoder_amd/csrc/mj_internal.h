@@ -36,6 +36,7 @@ struct MjDeviceBatch {
     uint32_t n_multi_cap;    /* capacity of the multi-sequence interval list */
     uint32_t n_idct_wg;      /* dequant+IDCT+colour workgroups */
     uint32_t want_planes;
+    uint32_t rgba;           /* 1: four bytes per pixel (R, G, B, 255) */
     uint32_t max_ntab;       /* largest Huffman table set in the batch (sizes the kernels' LDS) */
     uint32_t max_nac;        /* most AC tables in one set */
     uint32_t dbg;            /* timing experiments only: bit 0 skip write pass, bit 1 skip sync rounds, bit 2 skip coefficient stores */

@@ -183,7 +183,19 @@ struct __attribute__((aligned(4))) Rgb4 {
     uint32_t a, b, c;
 };
 
-__device__ __forceinline__ void store_quad(uint8_t *o, const uint32_t px[4], uint32_t gx, uint32_t X) {
+/* four pixels (0x00BBGGRR each) to `o`: twelve bytes of RGB24, or sixteen of R, G, B, 255 */
+__device__ __forceinline__ void store_quad(uint8_t *o, const uint32_t px[4], uint32_t gx, uint32_t X, bool rgba) {
+    if (rgba) {
+        if (gx + 4 <= X) {
+            *reinterpret_cast<uint4 *>(o) = make_uint4(px[0] | 0xFF000000u, px[1] | 0xFF000000u, px[2] | 0xFF000000u, px[3] | 0xFF000000u);
+        } else {
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {
+                if (gx + k < X) reinterpret_cast<uint32_t *>(o)[k] = px[k] | 0xFF000000u;
+            }
+        }
+        return;
+    }
     if (gx + 4 <= X) {
         Rgb4 v;
         v.a = px[0] | (px[1] << 24);
@@ -225,7 +237,8 @@ template <int SH, int SV>
 __device__ __forceinline__ void colour_fast(const uint8_t *s_smp, const ChromaRow *s_tcb, const ChromaRow *s_tcr, uint32_t bpm,
                                             uint32_t s0, uint32_t s1, uint32_t s2, uint32_t tile_w, uint32_t tile_h,
                                             uint32_t px0, uint32_t py0, uint32_t X, uint32_t Y, uint32_t pitch,
-                                            uint8_t *rgb) {
+                                            uint8_t *rgb, bool rgba) {
+    const uint32_t bpp = rgba ? 4u : 3u;
     constexpr int NC = 8 >> SH, HC = 4 >> SH, ROWS = 1 << SV;   /* chroma samples per patch row, per half of it */
     const uint32_t cols = tile_w / 8, prow_n = tile_h >> SV;
     const uint32_t dy = TPB / cols, dq = TPB - dy * cols;
@@ -295,7 +308,7 @@ __device__ __forceinline__ void colour_fast(const uint8_t *s_smp, const ChromaRo
                 }
                 /* rows of one tile are at most a few megabytes apart: 32-bit offsets from the
                  * tile's first row */
-                store_quad(rgb_tile + (__umul24(y + r, pitch) + 3u * (gx + 4 * h)), px, gx + 4 * h, X);
+                store_quad(rgb_tile + (__umul24(y + r, pitch) + bpp * (gx + 4 * h)), px, gx + 4 * h, X, rgba);
             }
         }
     }
@@ -464,6 +477,8 @@ __global__ __launch_bounds__(TPB, MJ_IDCT_WAVES) void mj_k_idct_colour(MjDeviceB
     uint32_t y = threadIdx.x / quads;
     uint32_t qx = threadIdx.x - y * quads;
     uint8_t *rgb = b.rgb + im.rgb_off;
+    const bool rgba = b.rgba != 0;
+    const uint32_t bpp = rgba ? 4u : 3u;
     if (im.ncs == 1) {
         for (; y < tile_h; y += dy, qx += dq) {
             if (qx >= quads) {
@@ -475,18 +490,8 @@ __global__ __launch_bounds__(TPB, MJ_IDCT_WAVES) void mj_k_idct_colour(MjDeviceB
             if (gy >= im.Y || gx >= im.X) continue;
             const uint32_t v = *reinterpret_cast<const uint32_t *>(s_smp + smp(sb0, hs0, x, y));
             const uint32_t a = v & 0xFF, bb = (v >> 8) & 0xFF, cc = (v >> 16) & 0xFF, d = v >> 24;
-            uint8_t *o = rgb + (uint64_t) gy * im.pitch + 3 * gx;
-            if (gx + 4 <= im.X) {
-                uint32_t *o32 = reinterpret_cast<uint32_t *>(o);
-                o32[0] = a | (a << 8) | (a << 16) | (bb << 24);
-                o32[1] = bb | (bb << 8) | (cc << 16) | (cc << 24);
-                o32[2] = cc | (d << 8) | (d << 16) | (d << 24);
-            } else {
-                const uint32_t px[4] = {a, bb, cc, d};
-                for (uint32_t k = 0; k < 4 && gx + k < im.X; k++) {
-                    o[3 * k] = o[3 * k + 1] = o[3 * k + 2] = (uint8_t) px[k];
-                }
-            }
+            const uint32_t px[4] = {a * 0x010101u, bb * 0x010101u, cc * 0x010101u, d * 0x010101u};
+            store_quad(rgb + (uint64_t) gy * im.pitch + bpp * gx, px, gx, im.X, rgba);
         }
         return;
     }
@@ -496,7 +501,7 @@ __global__ __launch_bounds__(TPB, MJ_IDCT_WAVES) void mj_k_idct_colour(MjDeviceB
                           im.comp[0].hsf == im.hmax && im.comp[0].vsf == im.vmax;
         if (same && ch != 3 && cv <= 2) {
 #define MJ_FAST(SH, SV)                                                                                          \
-    colour_fast<SH, SV>(s_smp, s_tcb, s_tcr, bpm, sb0, sb1, sb2, tile_w, tile_h, px0, py0, im.X, im.Y, im.pitch, rgb)
+    colour_fast<SH, SV>(s_smp, s_tcb, s_tcr, bpm, sb0, sb1, sb2, tile_w, tile_h, px0, py0, im.X, im.Y, im.pitch, rgb, rgba)
             if (cv == 1) {
                 if (ch == 1) MJ_FAST(0, 0);
                 else if (ch == 2) MJ_FAST(1, 0);
@@ -530,7 +535,7 @@ __global__ __launch_bounds__(TPB, MJ_IDCT_WAVES) void mj_k_idct_colour(MjDeviceB
             px[k] = ycc_to_rgb24(s_smp[smp(sb0, hs0, xx / qh0, y / qv0)], s_tcb[s_smp[smp(sb1, hs1, xx / qh1, y / qv1)]],
                                  s_tcr[s_smp[smp(sb2, hs2, xx / qh2, y / qv2)]]);
         }
-        store_quad(rgb + (uint64_t) gy * im.pitch + 3 * gx, px, gx, im.X);
+        store_quad(rgb + (uint64_t) gy * im.pitch + bpp * gx, px, gx, im.X, rgba);
     }
 }
 

@@ -324,3 +324,20 @@ def test_empty_and_unparsable_inputs_are_refused(ctx):
     b.decode()
     _check_image(b, 0, g["coefs"], None, g["rgb"], "after refusals")
     b.close()
+
+
+def test_rgba_output_is_rgb_plus_opaque_alpha(ctx):
+    """MJ_OUT_RGBA: the same pixels, four bytes each with alpha 255, rows of 4 * X bytes
+    (grey, every subsampling, widths that are not multiples of four)."""
+    names = ["c420_q85_100x75_ri3", "c422_q50_33x17", "c444_q75_opt_57x43", "g_q85_edges_48x48", "c420_q100_edges_40x40",
+             "C1_c420_q85_512x512"]
+    files, golds = zip(*[load_fixture(n) for n in names])
+    b = ctx.batch(list(files), binding.MJ_OUT_RGBA)
+    b.decode()
+    for i, (name, g) in enumerate(zip(names, golds)):
+        out = b.rgb(i)
+        assert out.shape == g["rgb"].shape[:2] + (4,), name
+        assert b.info(i).rgb_pitch == 4 * g["rgb"].shape[1], name
+        assert np.array_equal(out[..., :3], g["rgb"]), name
+        assert (out[..., 3] == 255).all(), name
+    b.close()
