@@ -53,6 +53,10 @@ struct mj_ctx {
     int device;
     hipStream_t own;
     hipStream_t stream;
+    /* page-locked staging for the entropy-coded bytes of the batch being built: the copy to
+     * HBM then runs at the bus rate; kept and grown from one batch to the next */
+    uint8_t *stage = nullptr;
+    size_t stage_cap = 0;
 };
 
 struct mj_batch {
@@ -143,6 +147,7 @@ void mj_destroy(mj_ctx *ctx) {
     (void) hipSetDevice(ctx->device);
     (void) hipStreamSynchronize(ctx->stream);
     (void) hipStreamDestroy(ctx->own);
+    if (ctx->stage) (void) hipHostFree(ctx->stage);
     delete ctx;
 }
 
@@ -330,13 +335,39 @@ static int batch_build(mj_ctx *ctx, std::vector<MjPrepared> &prep, uint32_t flag
     b->plane_bytes = plane_total;
 
     /* raw entropy bytes: staged on the host, one copy to HBM */
-    std::vector<uint8_t> raw(raw_total + 64, 0);
-    for (int i = 0; i < n; i++) memcpy(raw.data() + b->img[i].raw_off, prep[i].ent, b->img[i].raw_len);
+    const size_t raw_bytes = (size_t) raw_total + 64;
+    if (ctx->stage_cap < raw_bytes) {
+        if (ctx->stage) (void) hipHostFree(ctx->stage);
+        ctx->stage = nullptr;
+        ctx->stage_cap = 0;
+        const size_t cap = raw_bytes + raw_bytes / 4;
+        if (hipHostMalloc(reinterpret_cast<void **>(&ctx->stage), cap, hipHostMallocDefault) != hipSuccess) {
+            mj_batch_destroy(b);
+            return set_err("mj_batch_create: cannot allocate %zu bytes of page-locked staging memory", cap);
+        }
+        ctx->stage_cap = cap;
+    }
+    {
+        uint8_t *raw = ctx->stage;
+        uint64_t at = 0;
+        for (int i = 0; i < n; i++) {       /* the images' bytes, zeros in the padding between them */
+            const MjImageDev &im = b->img[i];
+            memset(raw + at, 0, (size_t) (im.raw_off - at));
+            memcpy(raw + im.raw_off, prep[i].ent, im.raw_len);
+            at = im.raw_off + im.raw_len;
+        }
+        memset(raw + at, 0, raw_bytes - (size_t) at);
+    }
 
     int rc = 0;
     rc |= dev_upload(b, &d.img, b->img);
     rc |= dev_upload(b, &d.sets, b->sets);
-    rc |= dev_upload(b, &d.raw, raw);
+    {
+        uint8_t *p = nullptr;
+        rc |= dev_alloc(b, &p, raw_bytes, false);
+        if (!rc && hipMemcpy(p, ctx->stage, raw_bytes, hipMemcpyHostToDevice) != hipSuccess) rc = -1;
+        d.raw = p;
+    }
     rc |= dev_upload(b, &d.tile_img, tile_img);
     rc |= dev_upload(b, &d.wg_img, wg_img);
     rc |= dev_upload(b, &d.idct_wg_img, idct_img);

@@ -142,7 +142,71 @@ static uint32_t entry_of(const MjHuffDev *t, uint32_t w) {
     return 0;
 }
 
+static void flatten_huff_build(const HuffTable *ht, int is_ac, MjHuffDev *out, MjHuffWalk *walk, MjHuffRun *pair, MjHuffPair *next);
+
+/* The images of a batch mostly carry the same few tables (an encoder's defaults): the
+ * last tables built are kept, keyed by what the DHT segment said, and copied instead of
+ * built again. */
+#define MJ_FLAT_CACHE 8
+typedef struct {
+    int used, is_ac, full;              /* full: the AC side tables were built too */
+    uint8_t len[16];
+    uint8_t syms[256];
+    MjHuffDev dev;
+    MjHuffWalk walk;
+    MjHuffRun run;
+    MjHuffPair next;
+} FlatCacheEntry;
+static _Thread_local FlatCacheEntry *flat_cache;   /* MJ_FLAT_CACHE entries, allocated on first use */
+static _Thread_local unsigned flat_cache_next;
+
 void mj_flatten_huff(const HuffTable *ht, int is_ac, MjHuffDev *out, MjHuffWalk *walk, MjHuffRun *pair, MjHuffPair *next) {
+    uint8_t len[16], syms[256];
+    int nsym = 0, keyed = 1;
+    memset(syms, 0, sizeof syms);
+    for (int l = 0; l < 16; l++) {
+        len[l] = ht->len[l];
+        for (int i = 0; i < ht->len[l]; i++) {
+            if (!ht->symbols[l] || nsym >= 256) {
+                keyed = 0;
+                break;
+            }
+            syms[nsym++] = ht->symbols[l][i];
+        }
+    }
+    if (keyed && !flat_cache) flat_cache = (FlatCacheEntry *) calloc(MJ_FLAT_CACHE, sizeof *flat_cache);
+    const int want_full = (pair != NULL && next != NULL);
+    if (keyed && flat_cache) {
+        for (int e = 0; e < MJ_FLAT_CACHE; e++) {
+            const FlatCacheEntry *c = &flat_cache[e];
+            if (c->used && c->is_ac == is_ac && (c->full || !want_full) && memcmp(c->len, len, 16) == 0 &&
+                memcmp(c->syms, syms, 256) == 0) {
+                *out = c->dev;
+                *walk = c->walk;
+                if (pair) *pair = c->run;
+                if (next) *next = c->next;
+                return;
+            }
+        }
+    }
+    flatten_huff_build(ht, is_ac, out, walk, pair, next);
+    if (keyed && flat_cache && (pair == NULL) == (next == NULL)) {
+        FlatCacheEntry *c = &flat_cache[flat_cache_next++ % MJ_FLAT_CACHE];
+        c->used = 1;
+        c->is_ac = is_ac;
+        c->full = want_full;
+        memcpy(c->len, len, 16);
+        memcpy(c->syms, syms, 256);
+        c->dev = *out;
+        c->walk = *walk;
+        if (want_full) {
+            c->run = *pair;
+            c->next = *next;
+        }
+    }
+}
+
+static void flatten_huff_build(const HuffTable *ht, int is_ac, MjHuffDev *out, MjHuffWalk *walk, MjHuffRun *pair, MjHuffPair *next) {
     memset(out, 0, sizeof *out);
     memset(walk, 0, sizeof *walk);
     if (pair) memset(pair, 0, sizeof *pair);
