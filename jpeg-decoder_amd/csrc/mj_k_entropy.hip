@@ -322,13 +322,53 @@ __global__ __launch_bounds__(SYNC_TPB, 8) void mj_k_entropy_sync(MjDeviceBatch b
 }
 
 /* ------------------------------------------------------------------------ */
+/* kernel 2a: the first cross-sequence pass, spread over the whole chip      */
+/* ------------------------------------------------------------------------ */
+/* Every sequence that is not the first of its interval is entered by the decoder that
+ * left the sequence before it: that decoder goes on here, one lane per such boundary and
+ * eight boundaries per workgroup, so that the (serial, lone-lane) decodes of all the
+ * boundaries of a long scan run on as many CUs as there are, not on the one CU of the
+ * interval's workgroup in mj_k_entropy_fix.  That kernel then finds the entry states it
+ * would have used already recorded in seq_seen, repeats only what changed since, and
+ * checks convergence as before. */
+__global__ __launch_bounds__(64) void mj_k_entropy_fix_first(MjDeviceBatch b) {
+    const uint32_t ii = b.wg_img[blockIdx.x];
+    const MjImageDev &im = b.img[ii];
+    const uint32_t n_seq = b.dyn[ii].n_seq;
+    const uint32_t sq = (blockIdx.x - im.wg_first) * MJ_WG_SEQS + threadIdx.x;     /* sequence of the image */
+    const bool boundary = threadIdx.x < MJ_WG_SEQS && sq < n_seq && b.seq_sub[im.seq_off + sq] != 0;
+    if (!__any(boundary)) return;
+    unsigned char *s_pairs = lds_after_dc(b, 0);
+    load_tables(b, im, s_pairs, true);
+    __syncthreads();
+    if (!boundary) return;
+    const MjScanCtx cx = make_ctx(b, im, s_pairs, true);
+    const uint32_t S = im.sub_bits, SQ = MJ_SEQ_LANES * im.lane_subs;
+    const uint32_t iv = b.seq_ivl[im.seq_off + sq], first = b.seq_sub[im.seq_off + sq];
+    const Geo g = interval_geo(b.ivl_start + im.ivl_off, iv, S, SQ);
+    MjSubRec *rec = b.rec + im.rec_off + (uint64_t) sq * SQ;       /* this sequence's records; the one before them is the entry */
+    const MjState e = rec[-1].exit;
+    b.seq_seen[im.seq_off + sq] = e;
+    uint32_t p = e.p, kc = e.kc;
+    const uint32_t n = min(g.nsub - first, (uint32_t) SQ);
+    for (uint32_t l = 0; l < n; l++) {
+        const LaneRec o = decode_nowrite(cx, p, kc, sub_end(g.b0, g.b1, g.nsub, first + l, S));
+        const MjState old = rec[l].exit;
+        store_rec(rec + l, o);
+        p = o.p;
+        kc = o.kc;
+        if (old.p == o.p && old.kc == o.kc) break;
+    }
+}
+
+/* ------------------------------------------------------------------------ */
 /* kernel 2: per long interval -- cross-sequence synchronisation            */
 /* ------------------------------------------------------------------------ */
 constexpr int FIX_TPB = 1024;
 
 __global__ __launch_bounds__(FIX_TPB) void mj_k_entropy_fix(MjDeviceBatch b) {
     __shared__ int s_changed;
-    __shared__ uint32_t s_part[FIX_TPB * 5];
+    __shared__ uint32_t s_part[FIX_TPB / 64];
     const uint32_t n_multi = min(*b.multi_count, b.n_multi_cap);
     if (blockIdx.x >= n_multi) return;
     const uint2 mi = b.multi[blockIdx.x];
@@ -353,7 +393,7 @@ __global__ __launch_bounds__(FIX_TPB) void mj_k_entropy_fix(MjDeviceBatch b) {
         for (uint32_t q = 1 + threadIdx.x; q < g.nseq; q += FIX_TPB) {
             const MjState e = rec[(uint64_t) q * SQ - 1].exit;
             const MjState seen = b.seq_seen[seq_first + q];
-            const bool redo = (iters == 0) || e.p != seen.p || e.kc != seen.kc;
+            const bool redo = e.p != seen.p || e.kc != seen.kc;   /* seen: what mj_k_entropy_fix_first, or the last iteration, started from */
             b.seq_flag[seq_first + q] = redo ? 1u : 0u;
             if (redo) {
                 b.seq_seen[seq_first + q] = e;
@@ -386,69 +426,90 @@ __global__ __launch_bounds__(FIX_TPB) void mj_k_entropy_fix(MjDeviceBatch b) {
         atomicMax(&b.stats[MJ_ST_FIXITERS], (unsigned long long) iters);
     }
 
-    /* Prefix over sequences: blocks and DC sums that precede each sequence.
-     * Each thread owns a contiguous chunk of sequences. */
-    const uint32_t per = (g.nseq + FIX_TPB - 1) / FIX_TPB;
-    const uint32_t q_lo = min(threadIdx.x * per, g.nseq), q_hi = min(q_lo + per, g.nseq);
-    uint32_t tnb = 0;
-    int32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
-    for (uint32_t q = q_lo; q < q_hi; q++) {
+    /* Prefix over sequences: blocks and DC sums that precede each sequence.  First the
+     * totals of every sequence, one wavefront per sequence at a time (its records are one
+     * contiguous run: coalesced 32-byte loads), parked in the sequence's entry; then an
+     * exclusive scan over the sequences by the whole workgroup. */
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    for (uint32_t q = wave; q < g.nseq; q += FIX_TPB / 64) {
         const uint32_t first = q * SQ;
         const uint32_t n = min(g.nsub - first, (uint32_t) SQ);
-        for (uint32_t l = 0; l < n; l++) {
-            const MjSubRec &r = rec[(uint64_t) first + l];
+        uint32_t tnb = 0;
+        int32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+        for (uint32_t l = lane; l < n; l += 64) {
+            const MjSubRec r = rec[(uint64_t) first + l];
             tnb += r.nb;
             t0 += r.dcsum[0];
             t1 += r.dcsum[1];
             t2 += r.dcsum[2];
             t3 += r.dcsum[3];
         }
-    }
-    s_part[threadIdx.x * 5 + 0] = tnb;
-    s_part[threadIdx.x * 5 + 1] = (uint32_t) t0;
-    s_part[threadIdx.x * 5 + 2] = (uint32_t) t1;
-    s_part[threadIdx.x * 5 + 3] = (uint32_t) t2;
-    s_part[threadIdx.x * 5 + 4] = (uint32_t) t3;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t a[5] = {0, 0, 0, 0, 0};
-        for (uint32_t t = 0; t < FIX_TPB; t++) {
-            for (int i = 0; i < 5; i++) {
-                const uint32_t v = s_part[t * 5 + i];
-                s_part[t * 5 + i] = a[i];
-                a[i] += v;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            tnb += __shfl_xor(tnb, d, 64);
+            t0 += __shfl_xor(t0, d, 64);
+            t1 += __shfl_xor(t1, d, 64);
+            t2 += __shfl_xor(t2, d, 64);
+            t3 += __shfl_xor(t3, d, 64);
+        }
+        if (lane == 0) {
+            MjSeqEntry se;
+            if (q == 0) {
+                se.entry.p = g.b0;
+                se.entry.kc = 0;
+            } else {
+                se.entry = rec[(uint64_t) q * SQ - 1].exit;
             }
+            se.blk = tnb;
+            se.pred[0] = t0;
+            se.pred[1] = t1;
+            se.pred[2] = t2;
+            se.pred[3] = t3;
+            se.pad_ = 0;
+            b.seq_entry[seq_first + q] = se;
         }
     }
     __syncthreads();
-    uint32_t anb = s_part[threadIdx.x * 5 + 0];
-    int32_t a0 = (int32_t) s_part[threadIdx.x * 5 + 1], a1 = (int32_t) s_part[threadIdx.x * 5 + 2];
-    int32_t a2 = (int32_t) s_part[threadIdx.x * 5 + 3], a3 = (int32_t) s_part[threadIdx.x * 5 + 4];
     const uint32_t blk_base = iv * im.ri * im.bpm;
-    for (uint32_t q = q_lo; q < q_hi; q++) {
-        MjSeqEntry se;
-        if (q == 0) {
-            se.entry.p = g.b0;
-            se.entry.kc = 0;
-        } else {
-            se.entry = rec[(uint64_t) q * SQ - 1].exit;
+    uint32_t carry[5] = {blk_base, 0, 0, 0, 0};
+    for (uint32_t q0 = 0; q0 < g.nseq; q0 += FIX_TPB) {
+        const uint32_t q = q0 + threadIdx.x;
+        uint32_t v[5] = {0, 0, 0, 0, 0};
+        if (q < g.nseq) {
+            const MjSeqEntry se = b.seq_entry[seq_first + q];
+            v[0] = se.blk;
+            v[1] = (uint32_t) se.pred[0];
+            v[2] = (uint32_t) se.pred[1];
+            v[3] = (uint32_t) se.pred[2];
+            v[4] = (uint32_t) se.pred[3];
         }
-        se.blk = blk_base + anb;
-        se.pred[0] = a0;
-        se.pred[1] = a1;
-        se.pred[2] = a2;
-        se.pred[3] = a3;
-        se.pad_ = 0;
-        b.seq_entry[seq_first + q] = se;
-        const uint32_t first = q * SQ;
-        const uint32_t n = min(g.nsub - first, (uint32_t) SQ);
-        for (uint32_t l = 0; l < n; l++) {
-            const MjSubRec &r = rec[(uint64_t) first + l];
-            anb += r.nb;
-            a0 += r.dcsum[0];
-            a1 += r.dcsum[1];
-            a2 += r.dcsum[2];
-            a3 += r.dcsum[3];
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            /* inclusive scan inside the wavefront, then the wavefronts' totals through LDS */
+            uint32_t inc = v[i];
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(inc, d, 64);
+                if (lane >= (uint32_t) d) inc += o;
+            }
+            __syncthreads();
+            if (lane == 63) s_part[wave] = inc;
+            __syncthreads();
+            uint32_t before = 0, total = 0;
+            for (uint32_t w = 0; w < FIX_TPB / 64; w++) {
+                const uint32_t t = s_part[w];
+                before += (w < wave) ? t : 0u;
+                total += t;
+            }
+            v[i] = carry[i] + before + inc - v[i];
+            carry[i] += total;
+        }
+        if (q < g.nseq) {
+            b.seq_entry[seq_first + q].blk = v[0];
+            b.seq_entry[seq_first + q].pred[0] = (int32_t) v[1];
+            b.seq_entry[seq_first + q].pred[1] = (int32_t) v[2];
+            b.seq_entry[seq_first + q].pred[2] = (int32_t) v[3];
+            b.seq_entry[seq_first + q].pred[3] = (int32_t) v[4];
         }
     }
 }
@@ -631,6 +692,7 @@ hipError_t mj_launch_entropy(const MjDeviceBatch &b, hipStream_t s) {
 
 hipError_t mj_launch_entropy_fix(const MjDeviceBatch &b, hipStream_t s) {
     if (b.n_multi_cap == 0 || b.n_entropy_wg == 0) return hipSuccess;
+    hipLaunchKernelGGL(mj_k_entropy_fix_first, dim3(b.n_entropy_wg), dim3(64), table_lds(b, 0) + (size_t) b.max_nac * sizeof(MjHuffRun), s, b);
     hipLaunchKernelGGL(mj_k_entropy_fix, dim3(b.n_multi_cap), dim3(FIX_TPB),
                        table_lds(b, 0) + (size_t) b.max_nac * sizeof(MjHuffRun), s, b);
     return hipGetLastError();

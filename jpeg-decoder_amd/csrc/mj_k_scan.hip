@@ -222,6 +222,9 @@ __global__ __launch_bounds__(TPB) void mj_k_scan_write(MjDeviceBatch b) {
 /* Per image: interval table tail, then the subsequence / sequence layout. */
 __global__ __launch_bounds__(TPB) void mj_k_layout(MjDeviceBatch b) {
     __shared__ uint32_t s_w[TPB / 64];
+    __shared__ uint4 s_big[TPB];
+    __shared__ uint32_t s_nbig;
+    if (threadIdx.x == 0) s_nbig = 0;
     const uint32_t ii = blockIdx.x;
     const MjImageDev &im = b.img[ii];
     MjImageDyn &dy = b.dyn[ii];
@@ -252,11 +255,18 @@ __global__ __launch_bounds__(TPB) void mj_k_layout(MjDeviceBatch b) {
         const uint32_t first = carry + block_excl_scan(nseq, s_w, &tot);
         if (iv < im.n_ivl) {
             ivl_seq[iv] = first;
-            for (uint32_t q = 0; q < nseq; q++) {
-                if (first + q < im.seq_cap) {
-                    b.seq_ivl[im.seq_off + first + q] = iv;
-                    b.seq_sub[im.seq_off + first + q] = q * SQ;
+            if (nseq <= 4) {
+                for (uint32_t q = 0; q < nseq; q++) {
+                    if (first + q < im.seq_cap) {
+                        b.seq_ivl[im.seq_off + first + q] = iv;
+                        b.seq_sub[im.seq_off + first + q] = q * SQ;
+                    }
                 }
+            } else {
+                /* a long interval (a scan without restart markers is one): its sequences
+                 * are filled in by the whole workgroup below */
+                const uint32_t slot = atomicAdd(&s_nbig, 1u);
+                s_big[slot] = make_uint4(iv, first, nseq, 0);
             }
             if (nseq > 1) {
                 const uint32_t slot = atomicAdd(b.multi_count, 1u);
@@ -265,6 +275,19 @@ __global__ __launch_bounds__(TPB) void mj_k_layout(MjDeviceBatch b) {
             atomicAdd(&b.stats[MJ_ST_SUBS], (unsigned long long) nsub);
         }
         carry += tot;
+        __syncthreads();
+        const uint32_t nbig = s_nbig;
+        for (uint32_t e = 0; e < nbig; e++) {
+            const uint4 big = s_big[e];
+            for (uint32_t q = threadIdx.x; q < big.z; q += TPB) {
+                if (big.y + q < im.seq_cap) {
+                    b.seq_ivl[im.seq_off + big.y + q] = big.x;
+                    b.seq_sub[im.seq_off + big.y + q] = q * SQ;
+                }
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_nbig = 0;
     }
     if (threadIdx.x == 0) {
         if (carry > im.seq_cap) {
