@@ -138,7 +138,6 @@ int64_t mj_emu_decode_coefs(const uint8_t *file, size_t len, int16_t *coefs, int
     cx.pairs = (const unsigned char *) set->run;
     cx.pair_stride = (uint32_t) sizeof(MjHuffRun);
     cx.coefs = coefs;
-    cx.wi_mask = 0xFFFFFFFFu;
     MjScanCtx wcx = cx;   /* the writing pass looks up second symbols, not runs */
     wcx.pairs = (const unsigned char *) set->next;
     wcx.pair_stride = (uint32_t) sizeof(MjHuffPair);

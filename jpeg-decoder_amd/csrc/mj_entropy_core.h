@@ -48,7 +48,6 @@ struct MjScanCtx {
     uint32_t slotw0, slotw1, slotw2; /* mj_slot_desc() of slot i in byte i & 3 of word i >> 2 (separate members: never indexed) */
     int16_t *coefs;              /* block 0 of the image; 64 int16 per block, zigzag order */
     uint32_t bpm;                /* blocks per MCU */
-    uint32_t wi_mask;            /* 0xFFFFFFFF; timing experiments narrow it so every lane reads the same few blocks */
 };
 
 /* fill cx.slotw from per-slot component / table indices */
@@ -126,13 +125,13 @@ struct MjQuad {
 MJ_HD MjQuad mj_load_quad(const MjScanCtx &cx, uint32_t block) {
     MjQuad q;
 #if defined(__HIP_DEVICE_COMPILE__)
-    const uint4 v = reinterpret_cast<const uint4 *>(cx.stream)[block & cx.wi_mask];
+    const uint4 v = reinterpret_cast<const uint4 *>(cx.stream)[block];
     q.w0 = v.x;
     q.w1 = v.y;
     q.w2 = v.z;
     q.w3 = v.w;
 #else
-    const uint32_t *s = cx.stream + 4u * (size_t) (block & cx.wi_mask);
+    const uint32_t *s = cx.stream + 4u * (size_t) block;
     q.w0 = s[0];
     q.w1 = s[1];
     q.w2 = s[2];
@@ -231,10 +230,9 @@ MJ_HD void mj_refill(MjLane &L) {
 }
 
 /* Per-component DC accumulators (decode.c:682-690; the int16 wrap is applied when a
- * value is stored).  Two homes: lane-private words in memory, acc[comp * stride] (LDS on
- * the device, where the component index costs one address computation and the addition
- * one LDS operation that nobody waits for) for the counting passes; four registers for
- * the writing pass, which needs the sum back at once. */
+ * value is stored).  Two homes: lane-private words in memory, acc[comp * stride], which
+ * the host emulation uses; and two registers holding the four sums modulo 2^16 (MjAccPk
+ * below), which the kernels use. */
 struct MjAccMem {
     int32_t *p;
     uint32_t stride;
@@ -248,7 +246,6 @@ struct MjAccMem {
 #endif
     }
 };
-
 
 /* The sums in registers, modulo 2^16, two to a word.  A predictor is only ever used
  * through the int16 it is stored as (decode.c:687-690), so every sum that feeds it may be

@@ -109,7 +109,6 @@ __device__ __forceinline__ MjScanCtx make_ctx(const MjDeviceBatch &b, const MjIm
     cx.pair_stride = runs ? (uint32_t) sizeof(MjHuffRun) : (uint32_t) sizeof(MjHuffPair);
     mj_ctx_slots(cx, im.bpm, im.blk_comp, im.blk_dc, im.blk_ac);
     cx.coefs = b.coefs + im.coef_off * 64;
-    cx.wi_mask = (b.dbg & 32u) ? 15u : 0xFFFFFFFFu;
     return cx;
 }
 
