@@ -341,3 +341,34 @@ def test_rgba_output_is_rgb_plus_opaque_alpha(ctx):
         assert np.array_equal(out[..., :3], g["rgb"]), name
         assert (out[..., 3] == 255).all(), name
     b.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_images_vs_oracle(ctx, oracle, seed):
+    """Seeded random shapes, samplings, qualities, restart intervals and noise levels in
+    mixed batches, both entropy modes: coefficients, planes and RGB bit-exact against the
+    CPU restatement.  (The same loop has been run over many thousands of images.)"""
+    rng = np.random.default_rng(seed)
+    samplings = ["4:4:4", "4:2:2", "4:2:0", "4:4:0", "4:1:1"]
+    files, meta = [], []
+    for _ in range(24):
+        grey = rng.random() < 0.15
+        w, h = int(rng.integers(1, 700)), int(rng.integers(1, 500))
+        if rng.random() < 0.08:
+            w, h = int(rng.integers(700, 2200)), int(rng.integers(500, 1500))
+        if grey:
+            w = max(8, w // 8 * 8)
+        samp = samplings[int(rng.integers(0, len(samplings)))]
+        q = int(rng.integers(15, 101))
+        ri = int(rng.choice([0, 0, 1, 2, 3, 7, 16, 40, 200]))
+        sigma = float(rng.choice([0.0, 2.0, 12.0, 40.0]))
+        img = J.synth.synth_image(w, h, seed=int(rng.integers(0, 1 << 30)), sigma=sigma, grey=grey)
+        files.append(J.synth.encode_jpeg(img, samp, q, ri))
+        meta.append((w, h, samp, q, ri, grey, sigma))
+    wants = [oracle.decode(d) for d in files]
+    for flags in (0, binding.MJ_ENTROPY_SERIAL):
+        b = ctx.batch(files, binding.MJ_WANT_PLANES | flags)
+        b.decode()
+        for i, o in enumerate(wants):
+            _check_image(b, i, o.coefs, o.planes, o.rgb, f"{meta[i]} flags={flags}")
+        b.close()
