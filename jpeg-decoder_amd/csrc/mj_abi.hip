@@ -57,6 +57,11 @@ struct mj_ctx {
      * HBM then runs at the bus rate; kept and grown from one batch to the next */
     uint8_t *stage = nullptr;
     size_t stage_cap = 0;
+    /* the device memory of the last batch destroyed, for the next one to move into: a
+     * batch is one allocation, and a caller that decodes batch after batch (or image after
+     * image through the drop-in entry points) allocates once */
+    void *arena = nullptr;
+    size_t arena_cap = 0;
 };
 
 struct mj_batch {
@@ -65,7 +70,9 @@ struct mj_batch {
     std::vector<MjImageDev> img;
     std::vector<mj_image_info> info;
     std::vector<MjHuffSet> sets;
-    std::vector<void *> allocs;
+    uint8_t *arena = nullptr;      /* every device buffer of the batch is a piece of this one allocation */
+    size_t arena_cap = 0, arena_used = 0;
+    bool measuring = false;        /* first pass over the buffer list: sizes only */
     MjDeviceBatch d{};
     uint64_t coef_bytes = 0, rgb_bytes = 0, plane_bytes = 0;
     std::vector<EventSet> pending, pool;
@@ -75,23 +82,39 @@ struct mj_batch {
 
 namespace {
 
+/* the context's page-locked staging buffer, at least `bytes` long (contents are not kept) */
+int stage_reserve(mj_ctx *ctx, size_t bytes) {
+    if (ctx->stage_cap >= bytes) return 0;
+    if (ctx->stage) (void) hipHostFree(ctx->stage);
+    ctx->stage = nullptr;
+    ctx->stage_cap = 0;
+    const size_t cap = bytes + bytes / 4;
+    if (hipHostMalloc(reinterpret_cast<void **>(&ctx->stage), cap, hipHostMallocDefault) != hipSuccess) {
+        return set_err("cannot allocate %zu bytes of page-locked staging memory", cap);
+    }
+    ctx->stage_cap = cap;
+    return 0;
+}
+
 template <typename T>
-int dev_alloc(mj_batch *b, T **out, uint64_t count, bool zero) {
-    void *p = nullptr;
+int dev_alloc(mj_batch *b, T **out, uint64_t count) {
     uint64_t bytes = count * sizeof(T);
     if (bytes == 0) bytes = 16;
-    HIP_TRY(hipMalloc(&p, bytes));
-    b->allocs.push_back(p);
-    if (zero) HIP_TRY(hipMemset(p, 0, bytes));
-    *out = reinterpret_cast<T *>(p);
+    bytes = align_up(bytes, 256);
+    *out = nullptr;
+    if (!b->measuring) {
+        if (b->arena_used + bytes > b->arena_cap) return set_err("mj_batch_create: internal error: arena too small");
+        *out = reinterpret_cast<T *>(b->arena + b->arena_used);
+    }
+    b->arena_used += bytes;
     return 0;
 }
 
 template <typename T>
 int dev_upload(mj_batch *b, const T **out, const std::vector<T> &v) {
     T *p = nullptr;
-    if (dev_alloc(b, &p, v.size(), false)) return -1;
-    if (!v.empty()) HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    if (dev_alloc(b, &p, v.size())) return -1;
+    if (p && !v.empty()) HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
     *out = p;
     return 0;
 }
@@ -148,6 +171,7 @@ void mj_destroy(mj_ctx *ctx) {
     (void) hipStreamSynchronize(ctx->stream);
     (void) hipStreamDestroy(ctx->own);
     if (ctx->stage) (void) hipHostFree(ctx->stage);
+    if (ctx->arena) (void) hipFree(ctx->arena);
     delete ctx;
 }
 
@@ -165,7 +189,19 @@ void mj_batch_destroy(mj_batch *b) {
     for (EventSet &es : b->pool) {
         for (hipEvent_t ev : es.ev) (void) hipEventDestroy(ev);
     }
-    for (void *p : b->allocs) (void) hipFree(p);
+    if (b->arena) {
+        mj_ctx *c = b->ctx;
+        if (c->arena && c->arena_cap < b->arena_cap) {
+            (void) hipFree(c->arena);
+            c->arena = nullptr;
+        }
+        if (!c->arena) {
+            c->arena = b->arena;
+            c->arena_cap = b->arena_cap;
+        } else {
+            (void) hipFree(b->arena);
+        }
+    }
     delete b;
 }
 
@@ -336,16 +372,9 @@ static int batch_build(mj_ctx *ctx, std::vector<MjPrepared> &prep, uint32_t flag
 
     /* raw entropy bytes: staged on the host, one copy to HBM */
     const size_t raw_bytes = (size_t) raw_total + 64;
-    if (ctx->stage_cap < raw_bytes) {
-        if (ctx->stage) (void) hipHostFree(ctx->stage);
-        ctx->stage = nullptr;
-        ctx->stage_cap = 0;
-        const size_t cap = raw_bytes + raw_bytes / 4;
-        if (hipHostMalloc(reinterpret_cast<void **>(&ctx->stage), cap, hipHostMallocDefault) != hipSuccess) {
-            mj_batch_destroy(b);
-            return set_err("mj_batch_create: cannot allocate %zu bytes of page-locked staging memory", cap);
-        }
-        ctx->stage_cap = cap;
+    if (stage_reserve(ctx, raw_bytes)) {
+        mj_batch_destroy(b);
+        return -1;
     }
     {
         uint8_t *raw = ctx->stage;
@@ -359,37 +388,71 @@ static int batch_build(mj_ctx *ctx, std::vector<MjPrepared> &prep, uint32_t flag
         memset(raw + at, 0, raw_bytes - (size_t) at);
     }
 
-    int rc = 0;
-    rc |= dev_upload(b, &d.img, b->img);
-    rc |= dev_upload(b, &d.sets, b->sets);
-    {
-        uint8_t *p = nullptr;
-        rc |= dev_alloc(b, &p, raw_bytes, false);
-        if (!rc && hipMemcpy(p, ctx->stage, raw_bytes, hipMemcpyHostToDevice) != hipSuccess) rc = -1;
-        d.raw = p;
+    /* the buffer list runs twice: once to add up the sizes, once to hand out the pieces */
+    auto place = [&]() -> int {
+        int rc = 0;
+        rc |= dev_upload(b, &d.img, b->img);
+        rc |= dev_upload(b, &d.sets, b->sets);
+        {
+            uint8_t *p = nullptr;
+            rc |= dev_alloc(b, &p, raw_bytes);
+            if (!rc && p && hipMemcpy(p, ctx->stage, raw_bytes, hipMemcpyHostToDevice) != hipSuccess) rc = -1;
+            d.raw = p;
+        }
+        rc |= dev_upload(b, &d.tile_img, tile_img);
+        rc |= dev_upload(b, &d.wg_img, wg_img);
+        rc |= dev_upload(b, &d.idct_wg_img, idct_img);
+        rc |= dev_upload(b, &d.idct_wg_first, idct_first);
+        rc |= dev_alloc(b, &d.dyn, (uint64_t) n);
+        rc |= dev_alloc(b, &d.cmp, cmp_total + 64);
+        rc |= dev_alloc(b, &d.tile_cnt, n_tiles);
+        rc |= dev_alloc(b, &d.tile_base, n_tiles);
+        rc |= dev_alloc(b, &d.ivl_start, n_ivl);
+        rc |= dev_alloc(b, &d.ivl_seq, n_ivl);
+        rc |= dev_alloc(b, &d.seq_ivl, n_seq);
+        rc |= dev_alloc(b, &d.seq_sub, n_seq);
+        rc |= dev_alloc(b, &d.rec, n_rec);
+        rc |= dev_alloc(b, &d.seq_entry, n_seq);
+        rc |= dev_alloc(b, &d.seq_seen, n_seq);
+        rc |= dev_alloc(b, &d.seq_flag, n_seq);
+        rc |= dev_alloc(b, &d.multi, n_multi);
+        rc |= dev_alloc(b, &d.multi_count, 4);
+        rc |= dev_alloc(b, &d.coefs, coef_blocks * 64);
+        rc |= dev_alloc(b, &d.rgb, rgb_total);
+        rc |= dev_alloc(b, &d.planes, d.want_planes ? plane_total : 0);
+        rc |= dev_alloc(b, &d.stats, (uint64_t) MJ_ST_COUNT);
+        return rc;
+    };
+    b->measuring = true;
+    b->arena_used = 0;
+    int rc = place();
+    if (!rc) {
+        const size_t need = b->arena_used;
+        if (ctx->arena && ctx->arena_cap >= need) {          /* move into what the last batch left */
+            b->arena = static_cast<uint8_t *>(ctx->arena);
+            b->arena_cap = ctx->arena_cap;
+            ctx->arena = nullptr;
+            ctx->arena_cap = 0;
+        } else {
+            if (ctx->arena) {
+                (void) hipFree(ctx->arena);
+                ctx->arena = nullptr;
+                ctx->arena_cap = 0;
+            }
+            void *p = nullptr;
+            if (hipMalloc(&p, need) != hipSuccess) {
+                mj_batch_destroy(b);
+                return set_err("mj_batch_create: cannot allocate %zu bytes of device memory", need);
+            }
+            b->arena = static_cast<uint8_t *>(p);
+            b->arena_cap = need;
+        }
+        /* everything starts at zero, whoever used the memory before */
+        if (hipMemset(b->arena, 0, need) != hipSuccess) rc = -1;
+        b->measuring = false;
+        b->arena_used = 0;
+        if (!rc) rc = place();
     }
-    rc |= dev_upload(b, &d.tile_img, tile_img);
-    rc |= dev_upload(b, &d.wg_img, wg_img);
-    rc |= dev_upload(b, &d.idct_wg_img, idct_img);
-    rc |= dev_upload(b, &d.idct_wg_first, idct_first);
-    rc |= dev_alloc(b, &d.dyn, (uint64_t) n, true);
-    rc |= dev_alloc(b, &d.cmp, cmp_total + 64, true);
-    rc |= dev_alloc(b, &d.tile_cnt, n_tiles, true);
-    rc |= dev_alloc(b, &d.tile_base, n_tiles, true);
-    rc |= dev_alloc(b, &d.ivl_start, n_ivl, true);
-    rc |= dev_alloc(b, &d.ivl_seq, n_ivl, true);
-    rc |= dev_alloc(b, &d.seq_ivl, n_seq, true);
-    rc |= dev_alloc(b, &d.seq_sub, n_seq, true);
-    rc |= dev_alloc(b, &d.rec, n_rec, true);
-    rc |= dev_alloc(b, &d.seq_entry, n_seq, true);
-    rc |= dev_alloc(b, &d.seq_seen, n_seq, true);
-    rc |= dev_alloc(b, &d.seq_flag, n_seq, true);
-    rc |= dev_alloc(b, &d.multi, n_multi, true);
-    rc |= dev_alloc(b, &d.multi_count, 4, true);
-    rc |= dev_alloc(b, &d.coefs, coef_blocks * 64, true);
-    rc |= dev_alloc(b, &d.rgb, rgb_total, true);
-    rc |= dev_alloc(b, &d.planes, d.want_planes ? plane_total : 0, true);
-    rc |= dev_alloc(b, &d.stats, (uint64_t) MJ_ST_COUNT, true);
     if (rc) {
         mj_batch_destroy(b);
         return -1;
@@ -496,7 +559,17 @@ int mj_batch_copy_rgb(mj_batch *b, int i, uint8_t *dst, size_t dst_pitch) {
     const size_t row = (size_t) (b->d.rgba ? 4 : 3) * im.X;
     if (dst_pitch < row) return set_err("mj_batch_copy_rgb: pitch smaller than a row");
     if (mj_batch_sync(b)) return -1;
-    HIP_TRY(hipMemcpy2D(dst, dst_pitch, b->d.rgb + im.rgb_off, im.pitch, row, im.Y, hipMemcpyDeviceToHost));
+    /* one contiguous copy into the context's page-locked buffer, then rows to the caller's
+     * pitch on the host (a pitched copy into pageable memory is several times slower) */
+    const size_t bytes = (size_t) im.pitch * im.Y;
+    if (bytes == 0) return 0;
+    if (stage_reserve(b->ctx, bytes)) return -1;
+    HIP_TRY(hipMemcpy(b->ctx->stage, b->d.rgb + im.rgb_off, bytes, hipMemcpyDeviceToHost));
+    if (dst_pitch == im.pitch) {
+        memcpy(dst, b->ctx->stage, (size_t) im.pitch * (im.Y - 1) + row);
+    } else {
+        for (uint32_t y = 0; y < im.Y; y++) memcpy(dst + (size_t) y * dst_pitch, b->ctx->stage + (size_t) y * im.pitch, row);
+    }
     return 0;
 }
 
