@@ -156,3 +156,28 @@ def test_damaged_headers_and_streams_are_rejected_or_decoded_never_crash():
             except RuntimeError:
                 rejected += 1
     assert done + rejected == 450 and done > 0 and rejected > 0
+
+
+def test_host_code_is_clean_under_sanitizers(tmp_path):
+    """The host parser, the table flattening and the emulated kernel algorithm, compiled with
+    AddressSanitizer + UBSan (leak check included) and fed a few thousand damaged files."""
+    import shutil
+    import subprocess
+    if not (shutil.which("gcc") and shutil.which("g++")):
+        pytest.skip("no host compiler")
+    pkg = os.path.join(ROOT, "jpeg-decoder_amd")
+    inc = ["-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(pkg, "csrc"), "-I" + os.path.join(pkg, "host")]
+    san = ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-g", "-O1"]
+    objs = []
+    for name in ("bitcursor", "segments", "flatten"):
+        obj = str(tmp_path / (name + ".o"))
+        subprocess.run(["gcc", "-std=c17", *san, *inc, "-c", os.path.join(pkg, "host", name + ".c"), "-o", obj], check=True)
+        objs.append(obj)
+    exe = str(tmp_path / "fuzz_host")
+    subprocess.run(["g++", "-std=c++17", *san, *inc, "-o", exe, os.path.join(ROOT, "tests", "fuzz", "fuzz_host.cpp"),
+                    os.path.join(pkg, "csrc", "mj_emu.cpp"), *objs, "-lm"], check=True)
+    files = [os.path.join(ROOT, "tests", "golden", n + ".jpg")
+             for n in ("c420_q85_100x75_ri3", "g_q75_72x40_ri4", "c422_q95_opt_136x40_ri5", "c444_q90_dqt16_56x40")]
+    r = subprocess.run([exe, "800", *files], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "runs 3200" in r.stdout
