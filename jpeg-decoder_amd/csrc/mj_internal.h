@@ -81,9 +81,11 @@ hipError_t mj_launch_idct_colour(const MjDeviceBatch &b, hipStream_t s);
 #define MJ_IDCT_MAX_BLOCKS 256
 /* MCUs per tile: at most MJ_IDCT_MAX_BLOCKS blocks (eight lanes work on a block, 64 blocks per pass). */
 static inline __host__ __device__ uint32_t mj_idct_tile_cap(uint32_t bpm, uint32_t hmax) {
-    (void) hmax;
+    /* the colour stage numbers groups of four pixels of a tile row by thread: at most
+     * MJ_IDCT_THREADS of them, i.e. a tile is at most 4 * MJ_IDCT_THREADS pixels wide */
     uint32_t tmax = MJ_IDCT_MAX_BLOCKS / bpm;
-    if (tmax > 64) tmax = 64;
+    const uint32_t wmax = (4u * MJ_IDCT_THREADS) / (8u * (hmax ? hmax : 1u));
+    if (tmax > wmax) tmax = wmax;
     return tmax ? tmax : 1;
 }
 static inline __host__ __device__ uint32_t mj_idct_tiles_x(uint32_t mcus_x, uint32_t bpm, uint32_t hmax) {
