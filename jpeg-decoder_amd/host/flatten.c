@@ -334,7 +334,11 @@ void mj_choose_split(uint64_t raw_len, uint32_t n_ivl, uint32_t *sub_bits, uint3
     } else {
         /* one wavefront per interval with a little headroom for uneven intervals */
         lane_bits = (avg + avg / 16 + MJ_SEQ_LANES - 1) / MJ_SEQ_LANES;
-        if (lane_bits < 128) lane_bits = 128;
+        /* short intervals: fewer, longer lanes -- every synchronisation round has a fixed
+         * cost, and 256 bits per round is where that stops to dominate */
+        uint32_t minb = env_u32("MJ_TUNE_MIN_LANE_BITS");
+        if (!minb) minb = 256;
+        if (lane_bits < minb) lane_bits = minb;
         if (lane_bits > 4096) lane_bits = 4096;
         /* records every ~512 bits: a decoder that continues past its own lane stops at the
          * first record it agrees with, so finer records mean less re-decoding */
