@@ -176,6 +176,11 @@ int decode_scan(Bitstream *bs, Image *img, FrameHeader *fh, ScanHeader *sh, Huff
 /* pixels: caller-owned RGB24, `pitch` bytes per row (may exceed 3*width). */
 int y_rgb(FrameHeader *fh, Image *img, uint8_t *pixels, uint16_t width, uint16_t height, uint16_t pitch);
 int ycbcr_rgb(FrameHeader *fh, Image *img, uint8_t *pixels, uint16_t width, uint16_t height, uint16_t pitch);
+/* colour_conversion.h:20-27 / colour_conversion.c:85-162: four-component (YCCK) files.
+ * The reference's viewer names it (jpeg_decoder.c:99-101), so the symbol exists; the GPU
+ * path decodes one- and three-component frames only, and this always returns -1 with a
+ * message on stderr (decode_jpeg_buffer has already refused such a file by then). */
+int yccb_rgb(FrameHeader *fh, Image *img, uint8_t *pixels, uint16_t width, uint16_t height, uint16_t pitch);
 int get_max_sf(FrameHeader *fh, uint8_t *max_hsf, uint8_t *max_vsf);
 
 #ifdef __cplusplus

@@ -33,7 +33,7 @@ COMPAT_SYMBOLS = [
     "print_component", "decode_scan_header", "print_scan_header", "print_image_component", "new_huff_tables",
     "decode_huff_tables", "free_huff_tables", "print_huff_tables", "print_huff_table", "zigzag",
     "decode_quant_table", "dequant_data_unit", "decode_restart_interval", "allocate_img", "free_img",
-    "decode_jpeg_buffer", "decode_scan", "y_rgb", "ycbcr_rgb", "get_max_sf",
+    "decode_jpeg_buffer", "decode_scan", "y_rgb", "ycbcr_rgb", "yccb_rgb", "get_max_sf",
 ]
 
 

@@ -23,11 +23,16 @@
 static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
 static mj_ctx *g_ctx = NULL;
 
-#define MJ_SIDE_SLOTS 64
-static struct {
+/* Every live Image made by allocate_img: the bytes behind each of its planes (Image
+ * itself records only the strides, decode.h:12-17) and, once a scan has been decoded
+ * into it, the batch that holds its GPU results.  Grows as needed; guarded by g_lock. */
+typedef struct {
     Image *img;
     mj_batch *batch;
-} g_side[MJ_SIDE_SLOTS];
+    size_t plane_bytes[4];
+} SideEntry;
+static SideEntry *g_side = NULL;
+static size_t g_side_n = 0, g_side_cap = 0;
 
 /* end of the caller's buffer while decode_jpeg_buffer is on the stack */
 static _Thread_local const uint8_t *t_buf_end = NULL;
@@ -45,50 +50,44 @@ static mj_ctx *default_ctx(void) {
     return g_ctx;
 }
 
-static int side_put(Image *img, mj_batch *b) {
-    for (int i = 0; i < MJ_SIDE_SLOTS; i++) {
-        if (g_side[i].img == img) {     /* a second scan into the same Image */
-            mj_batch_destroy(g_side[i].batch);
-            g_side[i].batch = b;
-            return 0;
-        }
-    }
-    for (int i = 0; i < MJ_SIDE_SLOTS; i++) {
-        if (!g_side[i].img) {
-            g_side[i].img = img;
-            g_side[i].batch = b;
-            return 0;
-        }
-    }
-    return -1;
-}
-
-static mj_batch *side_get(Image *img) {
-    for (int i = 0; i < MJ_SIDE_SLOTS; i++) {
-        if (g_side[i].img == img) return g_side[i].batch;
+static SideEntry *side_find(const Image *img) {
+    for (size_t i = 0; i < g_side_n; i++) {
+        if (g_side[i].img == img) return &g_side[i];
     }
     return NULL;
 }
 
-static void side_drop(Image *img) {
-    for (int i = 0; i < MJ_SIDE_SLOTS; i++) {
-        if (g_side[i].img == img) {
-            mj_batch_destroy(g_side[i].batch);
-            g_side[i].img = NULL;
-            g_side[i].batch = NULL;
-        }
+static SideEntry *side_add(Image *img) {
+    if (g_side_n == g_side_cap) {
+        const size_t cap = g_side_cap ? 2 * g_side_cap : 16;
+        SideEntry *t = (SideEntry *) realloc(g_side, cap * sizeof *t);
+        if (!t) return NULL;
+        g_side = t;
+        g_side_cap = cap;
     }
+    SideEntry *e = &g_side[g_side_n++];
+    memset(e, 0, sizeof *e);
+    e->img = img;
+    return e;
+}
+
+static void side_drop(Image *img) {
+    SideEntry *e = side_find(img);
+    if (!e) return;
+    if (e->batch) mj_batch_destroy(e->batch);
+    *e = g_side[--g_side_n];
 }
 
 /* ---- Image (decode.c:95-136) -------------------------------------------- */
-static uint16_t pad_to_mcu(uint16_t v, int unit) {
-    return (uint16_t) ((v % unit) ? v + unit - (v % unit) : v);
+static size_t pad_to_mcu(size_t v, size_t unit) {
+    return (v % unit) ? v + unit - (v % unit) : v;
 }
 
 Image *allocate_img(FrameHeader *fh) {
-    if (!fh || !fh->cs || fh->ncs == 0) return NULL;
+    if (!fh || !fh->cs || fh->ncs == 0 || fh->ncs > 4) return NULL;
     Image *img = (Image *) calloc(1, sizeof *img);
     if (!img) return NULL;
+    size_t bytes[4] = {0, 0, 0, 0};
     img->buf = (uint8_t **) calloc(fh->ncs, sizeof *img->buf);
     img->width = (int *) calloc(fh->ncs, sizeof *img->width);
     if (!img->buf || !img->width) goto fail;
@@ -96,14 +95,19 @@ Image *allocate_img(FrameHeader *fh) {
         const Component *c = &fh->cs[i];
         if (c->hsf == 0 || c->vsf == 0) goto fail;
         /* each plane is padded to whole MCUs */
-        size_t w = pad_to_mcu(c->x, 8 * c->hsf), h = pad_to_mcu(c->y, 8 * c->vsf);
-        img->buf[i] = (uint8_t *) calloc((w && h) ? w * h : 1, 1);
+        const size_t w = pad_to_mcu(c->x, 8u * c->hsf), h = pad_to_mcu(c->y, 8u * c->vsf);
+        bytes[i] = (w && h) ? w * h : 1;
+        img->buf[i] = (uint8_t *) calloc(bytes[i], 1);
         if (!img->buf[i]) goto fail;
         img->width[i] = (int) w;
-        img->n_du = (uint8_t) (i + 1);
     }
     img->n_du = fh->ncs;
     img->mcu = 0;
+    pthread_mutex_lock(&g_lock);
+    SideEntry *e = side_add(img);
+    if (e) memcpy(e->plane_bytes, bytes, sizeof bytes);
+    pthread_mutex_unlock(&g_lock);
+    if (!e) goto fail;
     return img;
 fail:
     if (img->buf) {
@@ -132,7 +136,8 @@ int decode_scan(Bitstream *bs, Image *img, FrameHeader *fh, ScanHeader *sh, Huff
     if (!bs || !img || !fh || !sh || !hts || !qts) return -1;
     const uint8_t *ent = bs->encoded_data;
     size_t ent_len;
-    if (t_buf_end && t_buf_end > ent) {
+    if (t_buf_end) {
+        if (t_buf_end <= ent) return -1;   /* the file ends with its scan header */
         ent_len = (size_t) (t_buf_end - ent);
     } else {
         /* called on its own: like the reference, trust the stream to end in a marker */
@@ -157,10 +162,17 @@ int decode_scan(Bitstream *bs, Image *img, FrameHeader *fh, ScanHeader *sh, Huff
     }
     mj_image_info inf;
     if (mj_batch_image_info(b, 0, &inf) != 0) goto out;
-    /* fill the caller's planes (write_data_unit, decode.c:517-531) */
+    SideEntry *se = side_find(img);
+    if (!se) {
+        fprintf(stderr, "mi355jpeg: decode_scan needs an Image made by allocate_img (its plane sizes are unknown otherwise)\n");
+        goto out;
+    }
+    /* fill the caller's planes (write_data_unit, decode.c:517-531): same stride and no
+     * more bytes than the plane was allocated with */
     for (int c = 0; c < inf.ncs && c < img->n_du; c++) {
-        if (img->width[c] != inf.plane_w[c]) {
-            fprintf(stderr, "mi355jpeg: Image plane %d has stride %d, expected %d\n", c, img->width[c], inf.plane_w[c]);
+        if (img->width[c] != inf.plane_w[c] || (size_t) inf.plane_w[c] * (size_t) inf.plane_h[c] > se->plane_bytes[c]) {
+            fprintf(stderr, "mi355jpeg: Image plane %d (stride %d, %zu bytes) does not fit the frame's %d x %d plane\n", c,
+                    img->width[c], se->plane_bytes[c], inf.plane_w[c], inf.plane_h[c]);
             goto out;
         }
         if (mj_batch_copy_plane(b, 0, c, img->buf[c]) != 0) {
@@ -174,10 +186,8 @@ int decode_scan(Bitstream *bs, Image *img, FrameHeader *fh, ScanHeader *sh, Huff
     bs->offset = 0;
     int64_t mcus = (int64_t) inf.mcus_x * inf.mcus_y;
     img->mcu = (uint16_t) (mcus > 65535 ? 65535 : mcus);
-    if (side_put(img, b) != 0) {
-        fprintf(stderr, "mi355jpeg: too many live Images (free_img releases them)\n");
-        goto out;
-    }
+    if (se->batch) mj_batch_destroy(se->batch);   /* a second scan into the same Image */
+    se->batch = b;
     b = NULL; /* now owned by the side table */
     rc = 0;
 out:
@@ -222,13 +232,15 @@ int decode_jpeg_buffer(uint8_t *buf, size_t len, FrameHeader *fh, Image **img) {
             case 0xC0:
             case 0xC1:
                 if (have_fh) free_frame_header(fh);
+                have_fh = 0;
                 if (decode_frame_header(m == 0xC0 ? BDCT : ESDCTHC, &bs, fh) != 0) { rc = -1; break; }
                 have_fh = 1;
                 print_frame_header(fh);
-                if (!im) {
-                    im = allocate_img(fh);
-                    if (!im) rc = -1;
-                }
+                /* the planes always match the frame header in force (the reference keeps the
+                 * Image of the first SOF, decode.c:179-185, whatever a later one says) */
+                if (im) free_img(im);
+                im = allocate_img(fh);
+                if (!im) rc = -1;
                 break;
             case 0xC2: case 0xC3: case 0xC5: case 0xC6: case 0xC7: case 0xC9: case 0xCA: case 0xCB:
             case 0xCD: case 0xCE: case 0xCF:
@@ -243,7 +255,7 @@ int decode_jpeg_buffer(uint8_t *buf, size_t len, FrameHeader *fh, Image **img) {
                 if (decode_huff_tables(&bs, &hts) != 0) rc = -1;
                 break;
             case 0xDB:
-                decode_quant_table(&bs, &qts);
+                if (decode_quant_table(&bs, &qts) != 0) { rc = -1; break; }
                 have_qts = 1;
                 break;
             case 0xDC:
@@ -298,7 +310,8 @@ static int copy_rgb_out(Image *img, uint8_t *pixels, uint16_t width, uint16_t he
     if (!img || !pixels) return -1;
     int rc = -1;
     pthread_mutex_lock(&g_lock);
-    mj_batch *b = side_get(img);
+    SideEntry *se = side_find(img);
+    mj_batch *b = se ? se->batch : NULL;
     mj_image_info inf;
     if (!b) {
         fprintf(stderr, "mi355jpeg: Image was not produced by this library's decode_scan (no GPU result to convert)\n");
@@ -328,4 +341,15 @@ int ycbcr_rgb(FrameHeader *fh, Image *img, uint8_t *pixels, uint16_t width, uint
 int y_rgb(FrameHeader *fh, Image *img, uint8_t *pixels, uint16_t width, uint16_t height, uint16_t pitch) {
     (void) fh;
     return copy_rgb_out(img, pixels, width, height, pitch, 1);
+}
+
+int yccb_rgb(FrameHeader *fh, Image *img, uint8_t *pixels, uint16_t width, uint16_t height, uint16_t pitch) {
+    (void) fh;
+    (void) img;
+    (void) pixels;
+    (void) width;
+    (void) height;
+    (void) pitch;
+    fprintf(stderr, "mi355jpeg: four-component (YCCK) frames are not decoded by the GPU path\n");
+    return -1;
 }

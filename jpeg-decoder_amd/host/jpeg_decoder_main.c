@@ -18,8 +18,14 @@
 #include <time.h>
 #include <unistd.h>
 
+/* the include list of the reference's viewer, name for name (jpeg_decoder.c:14-21) */
 #include "colour_conversion.h"
+#include "debug.h"
 #include "decode.h"
+#include "frame_header.h"
+#include "huff_table.h"
+#include "restart_interval.h"
+#include "scan_header.h"
 
 static double now_s(void) {
     struct timespec t;
@@ -51,6 +57,7 @@ int main(int argc, char **argv) {
         perror("mmap");
         return 1;
     }
+    debug_print("length: %lu\n", (unsigned long) st.st_size);   /* jpeg_decoder.c:48 */
     uint8_t *pixels = NULL;
     uint16_t width = 0, height = 0, pitch = 0;
     double t0 = now_s();
@@ -64,11 +71,13 @@ int main(int argc, char **argv) {
         }
         width = fh.X;
         height = fh.Y;
-        pitch = (uint16_t) (3 * width);
+        /* rows as an SDL RGB24 surface lays them out: padded to four bytes (jpeg_decoder.c:62-77) */
+        pitch = (uint16_t) ((3u * width + 3u) & ~3u);
         if (!pixels) pixels = (uint8_t *) calloc((size_t) pitch * height, 1);
         int rc = -1;
         if (fh.ncs == 1) rc = y_rgb(&fh, img, pixels, width, height, pitch);
         else if (fh.ncs == 3) rc = ycbcr_rgb(&fh, img, pixels, width, height, pitch);
+        else if (fh.ncs == 4) rc = yccb_rgb(&fh, img, pixels, width, height, pitch);
         free_img(img);
         free_frame_header(&fh);
         if (rc != 0) {
@@ -78,7 +87,9 @@ int main(int argc, char **argv) {
     }
     double dt = now_s() - t0;
     uint64_t h = 1469598103934665603ull;
-    for (size_t i = 0; i < (size_t) pitch * height; i++) h = (h ^ pixels[i]) * 1099511628211ull;
+    for (size_t y = 0; y < height; y++) {      /* the pixels, not the row padding */
+        for (size_t i = 0; i < (size_t) 3 * width; i++) h = (h ^ pixels[y * pitch + i]) * 1099511628211ull;
+    }
     printf("%s: %ux%u rgb24 fnv1a=%016llx  %.3f ms/decode\n", path, width, height, (unsigned long long) h,
            1e3 * dt / repeats);
     if (out) {
@@ -88,7 +99,7 @@ int main(int argc, char **argv) {
             return 1;
         }
         fprintf(f, "P6\n%u %u\n255\n", width, height);
-        fwrite(pixels, 1, (size_t) pitch * height, f);
+        for (size_t y = 0; y < height; y++) fwrite(pixels + y * pitch, 1, (size_t) 3 * width, f);
         fclose(f);
     }
     free(pixels);

@@ -6,6 +6,7 @@
  * descriptors by flatten.c; nothing here touches pixel or entropy data.
  */
 #include <math.h>
+#include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -134,7 +135,8 @@ int32_t decode_scan_header(Bitstream *bs, ScanHeader *sh) {
         return -1;
     }
     sh->nics = next_byte(bs);
-    if (sh->nics == 0 || sh->nics > 4) {
+    /* the fields read below are 2 * nics + 3 bytes: the segment must hold them */
+    if (sh->nics == 0 || sh->nics > 4 || len < 6 + 2 * sh->nics) {
         return -1;
     }
     for (int i = 0; i < sh->nics; i++) {
@@ -182,12 +184,24 @@ int32_t decode_huff_tables(Bitstream *bs, HuffTables *hts) {
     }
     uint8_t *end = bs->encoded_data + len - 2;
     while (bs->encoded_data < end) {
+        /* every read below stays inside the segment: the class/id byte and the sixteen
+         * counts first, then exactly as many symbol bytes as the counts add up to */
+        if (end - bs->encoded_data < 1 + MAX_CODE_LEN) {
+            return -1;
+        }
         uint8_t tc_th = next_byte(bs);
         uint8_t cls = tc_th >> 4, id = tc_th & 0xF;
         if (cls >= TC_NUM || id >= MAX_TABLES || id > hts->nDCAC) {
             return -1;
         }
         HuffTable *ht = &hts->DCAC[cls][id];
+        uint32_t total = 0;
+        for (int l = 0; l < MAX_CODE_LEN; l++) {
+            total += bs->encoded_data[l];
+        }
+        if (total > 256 || (ptrdiff_t) total > end - (bs->encoded_data + MAX_CODE_LEN)) {
+            return -1;
+        }
         for (int l = 0; l < MAX_CODE_LEN; l++) {
             ht->len[l] = next_byte(bs);
         }
@@ -265,11 +279,13 @@ int32_t decode_quant_table(Bitstream *bs, QuantTables *qts) {
     }
     int remaining = len - 2;
     while (remaining >= 65) {
-        uint8_t pq_tq = next_byte(bs);
+        uint8_t pq_tq = get_byte(bs);
         uint8_t prec = pq_tq >> 4, id = pq_tq & 0xF;
-        if (id > 3) {
+        /* Pq is 0 (8-bit entries) or 1 (16-bit); a table never runs past its segment */
+        if (id > 3 || prec > 1 || remaining < (prec ? 129 : 65)) {
             return -1;
         }
+        next_byte(bs);
         QuantTable *qt = &qts->tables[id];
         qt->precision = prec;
         /* the file lists entries in zigzag order; they are kept in natural order */

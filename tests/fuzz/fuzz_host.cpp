@@ -11,6 +11,44 @@
 
 extern "C" long long mj_emu_decode_coefs(const uint8_t *data, size_t len, int16_t *out, long long cap, uint32_t force,
                                          long long *stats);
+// the drop-in walker (decode_host.c) over stub_abi.c: runs up to the scan, where the stub refuses
+extern "C" int decode_jpeg_buffer(uint8_t *buf, size_t len, void *fh, void **img);
+extern "C" void free_img(void *img);
+extern "C" int32_t free_frame_header(void *fh);
+
+// Every input is handed over in an allocation of exactly its size, so that a read one byte
+// past the end lands in a sanitizer red zone (a shrunk std::vector keeps its capacity).
+static long long run_exact(const std::vector<uint8_t> &d, int16_t *out, long long cap, uint32_t force, long long *st) {
+    uint8_t *p = (uint8_t *) malloc(d.size() ? d.size() : 1);
+    if (!p) abort();
+    memcpy(p, d.data(), d.size());
+    const long long n = mj_emu_decode_coefs(p, d.size(), out, cap, force, st);
+    alignas(8) unsigned char fh[64];
+    memset(fh, 0, sizeof fh);
+    int32_t minus1 = -1;
+    memcpy(fh, &minus1, 4);
+    void *img = nullptr;
+    // a file cut before its scan "decodes" to blank planes, as in the reference (decode.c:417-423)
+    if (decode_jpeg_buffer(p, d.size(), fh, &img) == 0) {
+        free_img(img);
+        free_frame_header(fh);
+    }
+    free(p);
+    return n;
+}
+
+// segments [pos, pos + 2 + len) of the marker `m` in the headers of a good file
+static std::vector<size_t> find_segments(const std::vector<uint8_t> &g, size_t hdr, uint8_t m) {
+    std::vector<size_t> v;
+    size_t i = 2;
+    while (i + 4 <= hdr) {
+        if (g[i] != 0xFF) break;
+        const size_t len = ((size_t) g[i + 2] << 8) | g[i + 3];
+        if (g[i + 1] == m) v.push_back(i);
+        i += 2 + len;
+    }
+    return v;
+}
 
 static std::vector<uint8_t> slurp(const char *p) {
     std::vector<uint8_t> v;
@@ -45,7 +83,42 @@ int main(int argc, char **argv) {
         const size_t ent = good.size() - hdr;
         for (int v = 0; v < iters; v++) {
             std::vector<uint8_t> d = good;
-            switch (v % 8) {
+            switch (v % 11) {
+                case 8: {   // a table segment is the last thing in the file, its counts / precision damaged
+                    const std::vector<size_t> segs = find_segments(good, hdr, (rnd() & 1) ? 0xC4 : 0xDB);
+                    if (segs.empty()) break;
+                    const size_t at = segs[rnd() % segs.size()];
+                    const size_t len = ((size_t) good[at + 2] << 8) | good[at + 3];
+                    d.resize(at + 2 + len);
+                    const size_t k = at + 4 + rnd() % (len - 2);
+                    d[k] = (rnd() & 1) ? 0xFF : (uint8_t) rnd();
+                    if (rnd() & 1) d[at + 4] = (uint8_t) (0x10 | (d[at + 4] & 0x0F));   // Pq = 1 / class AC
+                    break;
+                }
+                case 9: {   // ... and claims to be shorter or longer than it is
+                    const std::vector<size_t> segs = find_segments(good, hdr, (rnd() & 1) ? 0xC4 : 0xDB);
+                    if (segs.empty()) break;
+                    const size_t at = segs[rnd() % segs.size()];
+                    const size_t len = ((size_t) good[at + 2] << 8) | good[at + 3];
+                    const size_t keep = 4 + rnd() % (len - 1);
+                    d.resize(at + keep);
+                    const size_t claim = 2 + rnd() % (keep - 1);
+                    d[at + 2] = (uint8_t) (claim >> 8);
+                    d[at + 3] = (uint8_t) claim;
+                    for (size_t k = at + 4; k < d.size() && k < at + 21; k++) if (rnd() & 1) d[k] = 0xFF;
+                    break;
+                }
+                case 10: {  // the smallest such file: SOI and one table segment whose counts are all 0xFF
+                    const bool dht = (rnd() & 1) != 0;
+                    const size_t body = dht ? 17 + rnd() % 4 : 1 + rnd() % 130;
+                    d.assign(4 + 2 + body, 0xFF);
+                    d[1] = 0xD8;
+                    d[3] = dht ? 0xC4 : 0xDB;
+                    d[4] = (uint8_t) ((body + 2) >> 8);
+                    d[5] = (uint8_t) (body + 2);
+                    d[6] = dht ? (uint8_t) (rnd() & 0x11) : (uint8_t) ((rnd() % 3) << 4);
+                    break;
+                }
                 case 0: d[2 + rnd() % (hdr - 2)] = (uint8_t) rnd(); break;                      // a header byte
                 case 1: d[2 + rnd() % (hdr - 2)] ^= (uint8_t) (1u << (rnd() % 8)); break;       // a header bit
                 case 2: d.resize(2 + rnd() % hdr); break;                                       // cut inside the headers
@@ -56,7 +129,7 @@ int main(int argc, char **argv) {
                 default: { size_t p = hdr + rnd() % (ent - 4); d[p] = 0xFF; d[p + 1] = (uint8_t) (0xD0 + rnd() % 8); break; }
             }
             const uint32_t force = (v % 3 == 0) ? 0u : (v % 3 == 1) ? (128u | (1u << 16)) : (256u | (2u << 16));
-            const long long n = mj_emu_decode_coefs(d.data(), d.size(), out.data(), 20000, force, st);
+            const long long n = run_exact(d, out.data(), 20000, force, st);
             runs++;
             if (n < 0) rejected++;
         }

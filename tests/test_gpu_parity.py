@@ -372,3 +372,56 @@ def test_random_images_vs_oracle(ctx, oracle, seed):
         for i, o in enumerate(wants):
             _check_image(b, i, o.coefs, o.planes, o.rgb, f"{meta[i]} flags={flags}")
         b.close()
+
+
+def _fnv1a(data):
+    h = 1469598103934665603
+    for byte in data:
+        h = ((h ^ byte) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def test_headless_jpeg_decoder_executable_on_config1():
+    """BASELINE config 1: the 512x512 4:2:0 file decoded by the jpeg_decoder executable (the
+    reference viewer's call sequence, jpeg_decoder.c:44-104, without the SDL window) in a
+    child process; the checksum it prints is that of the reference's RGB."""
+    import os
+    import re
+    import subprocess
+    from conftest import GOLDEN, ROOT
+    exe = os.path.join(ROOT, "jpeg-decoder_amd", "jpeg_decoder")
+    assert os.path.exists(exe), "jpeg_decoder is not built (run __graft_entry__.build())"
+    _, g = load_fixture("C1_c420_q85_512x512")
+    r = subprocess.run([exe, os.path.join(GOLDEN, "C1_c420_q85_512x512.jpg"), "-n", "3"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    m = re.search(r"(\d+)x(\d+) rgb24 fnv1a=([0-9a-f]{16})", r.stdout)
+    assert m, r.stdout
+    assert (int(m.group(1)), int(m.group(2))) == (512, 512)
+    assert int(m.group(3), 16) == _fnv1a(np.ascontiguousarray(g["rgb"]).tobytes())
+
+
+def test_many_live_images_through_the_dropin_entry_points(ctx):
+    """More Images alive at once than any fixed table would hold: each keeps its own GPU
+    result until free_img (the reference has no such limit either, decode.c:95-136)."""
+    lib = J.load_library()
+    data, g = load_fixture("c420_q85_64x48")
+    buf = C.create_string_buffer(data, len(data) + 16)
+    lib.decode_jpeg_buffer.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(_FrameHeader), C.POINTER(C.POINTER(_Image))]
+    lib.ycbcr_rgb.argtypes = [C.POINTER(_FrameHeader), C.POINTER(_Image), C.c_void_p, C.c_uint16, C.c_uint16, C.c_uint16]
+    lib.free_img.argtypes = [C.POINTER(_Image)]
+    lib.free_img.restype = None
+    lib.free_frame_header.argtypes = [C.POINTER(_FrameHeader)]
+    live = []
+    for _ in range(80):
+        fh = _FrameHeader()
+        fh.process = -1
+        img = C.POINTER(_Image)()
+        assert lib.decode_jpeg_buffer(buf, len(data), C.byref(fh), C.byref(img)) == 0
+        live.append((fh, img))
+    H, W = g["rgb"].shape[:2]
+    for fh, img in live[::-1]:
+        pixels = np.zeros((H, 3 * W), np.uint8)
+        assert lib.ycbcr_rgb(C.byref(fh), img, pixels.ctypes.data, W, H, 3 * W) == 0
+        assert np.array_equal(pixels.reshape(H, W, 3), g["rgb"])
+        lib.free_img(img)
+        lib.free_frame_header(C.byref(fh))
