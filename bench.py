@@ -185,7 +185,6 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     flags = binding.MJ_TIMING | (binding.MJ_ENTROPY_SERIAL if args.serial_entropy else 0)
-    flags |= int(os.environ.get("MJ_DEBUG_FLAGS", "0"), 0) << 16   # timing experiments only (results invalid)
     n_streams = max(1, min(args.streams, len(files)))
     ctxs = [J.Context(local_rank) for _ in range(n_streams)]       # one HIP stream each
     t0 = time.perf_counter()

@@ -38,6 +38,7 @@ typedef struct mj_batch mj_batch;
 #define MJ_TIMING      0x2u   /* bracket every kernel with HIP events on the batch stream */
 #define MJ_ENTROPY_SERIAL 0x4u /* diagnostic: one lane per restart interval, no subsequence sync */
 #define MJ_OUT_RGBA    0x8u   /* pixels leave as R, G, B, 255 (four bytes) instead of RGB24; rgb_pitch = 4 * X */
+#define MJ_FLAGS_ALL   0xFu   /* any other bit is refused */
 
 typedef struct {
     int32_t X, Y;            /* frame size in pixels */
@@ -79,7 +80,8 @@ int mj_set_stream(mj_ctx *ctx, void *hip_stream);
  * decode_huff_tables, decode_quant_table, decode_restart_interval,
  * decode_scan_header -- the reference's decode.c:160-415 marker walk), flatten
  * their tables, allocate device buffers and copy the entropy-coded bytes to HBM.
- * bufs[i] is borrowed for the duration of the call only. */
+ * bufs[i] is borrowed for the duration of the call only.  Device memory is not cleared:
+ * where a damaged stream leaves blocks undecoded, the outputs hold whatever was there. */
 int mj_batch_create(mj_ctx *ctx, const uint8_t *const *bufs, const size_t *lens, int n, uint32_t flags,
                     mj_batch **out);
 /* A batch of one image from already-parsed structs: what the reference hands to
@@ -90,6 +92,28 @@ int mj_batch_create_scan(mj_ctx *ctx, const uint8_t *entropy, size_t entropy_len
                          const ScanHeader *sh, const HuffTables *hts, const QuantTables *qts, RestartInterval ri,
                          uint32_t flags, mj_batch **out);
 void mj_batch_destroy(mj_batch *b);
+
+/* Page-locked host memory for JPEG files: entropy-coded bytes in such memory (or in
+ * memory the caller registered with the HIP runtime) are copied to HBM straight from
+ * where they lie; bytes in pageable memory are gathered in a staging buffer first. */
+void *mj_host_alloc(size_t bytes);
+void mj_host_free(void *p);
+
+/* A stream of batches, for callers that decode batch after batch (the role of the
+ * reference's mmap -> decode_jpeg_buffer hand-off, jpeg_decoder.c:44-55, at batch
+ * granularity).  mj_pipe_submit parses the files, enqueues the copy of their
+ * entropy-coded bytes on the context's copy stream and the decode behind it on the
+ * context's stream, and returns without waiting: the host work and the copy of batch
+ * k + 1 run while batch k decodes.  `depth` batches are in flight at most; each has
+ * its own device memory, allocated on first use and reused from then on.  *out is
+ * owned by the pipeline and is recycled by the depth-th submit after it (that submit
+ * waits for its decode first): read results (mj_batch_sync, mj_batch_device_rgb,
+ * copies, status) before then, and do not destroy it.  bufs[i] must stay valid and
+ * unchanged until mj_batch_sync(*out) returns.  Flags as for mj_batch_create. */
+typedef struct mj_pipe mj_pipe;
+int mj_pipe_create(mj_ctx *ctx, int depth, uint32_t flags, mj_pipe **out);
+int mj_pipe_submit(mj_pipe *p, const uint8_t *const *bufs, const size_t *lens, int n, mj_batch **out);
+void mj_pipe_destroy(mj_pipe *p);
 
 /* Enqueue the whole hot path for the batch on the stream (asynchronous).  Inputs
  * are already resident in HBM; outputs (coefficients, RGB, optional planes) stay

@@ -26,6 +26,7 @@ ABI_SYMBOLS = [
     "mj_batch_decode", "mj_batch_sync", "mj_batch_size", "mj_batch_image_info", "mj_batch_status",
     "mj_batch_device_rgb", "mj_batch_device_coefs", "mj_batch_copy_rgb", "mj_batch_copy_coefs",
     "mj_batch_copy_plane", "mj_batch_kernel_ms", "mj_batch_reset_timing", "mj_batch_entropy_stats",
+    "mj_host_alloc", "mj_host_free", "mj_pipe_create", "mj_pipe_submit", "mj_pipe_destroy",
 ]
 COMPAT_SYMBOLS = [
     "get_byte", "next_byte", "next_bit", "next_bit_size", "check_marker", "next_byte_restart_marker", "progress",
@@ -85,6 +86,14 @@ def load_library():
     lib.mj_batch_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
     lib.mj_batch_reset_timing.argtypes = [vp]
     lib.mj_batch_entropy_stats.argtypes = [vp, C.POINTER(C.c_int64)]
+    lib.mj_host_alloc.argtypes = [C.c_size_t]
+    lib.mj_host_alloc.restype = vp
+    lib.mj_host_free.argtypes = [vp]
+    lib.mj_host_free.restype = None
+    lib.mj_pipe_create.argtypes = [vp, i32, u32, C.POINTER(vp)]
+    lib.mj_pipe_submit.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), i32, C.POINTER(vp)]
+    lib.mj_pipe_destroy.argtypes = [vp]
+    lib.mj_pipe_destroy.restype = None
     _lib = lib
     return lib
 
@@ -110,6 +119,10 @@ class Context:
     def batch(self, files, flags=0):
         return Batch(self, files, flags)
 
+    def pipe(self, depth=2, flags=0):
+        return Pipe(self, depth, flags)
+
+
     def close(self):
         if self.h:
             for b in list(self._batches):
@@ -124,20 +137,73 @@ class Context:
             pass
 
 
+class PinnedFiles:
+    """JPEG files copied into one block of page-locked host memory (mj_host_alloc), each
+    starting on a 64-byte boundary: what a caller that wants the copy to HBM to run straight
+    from its buffers hands to Batch / Pipe.submit."""
+
+    def __init__(self, files):
+        self.lib = load_library()
+        offs, at = [], 0
+        for f in files:
+            offs.append(at)
+            at += (len(f) + 63) // 64 * 64
+        self.bytes = max(at, 64)
+        self.base = self.lib.mj_host_alloc(self.bytes)
+        if not self.base:
+            raise RuntimeError("mj_host_alloc failed: " + (self.lib.mj_last_error() or b"?").decode())
+        self.lens = [len(f) for f in files]
+        self.ptrs = [self.base + o for o in offs]
+        for p, f in zip(self.ptrs, files):
+            C.memmove(p, f, len(f))
+
+    def __len__(self):
+        return len(self.lens)
+
+    def close(self):
+        if self.base:
+            self.lib.mj_host_free(self.base)
+            self.base = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _file_args(files):
+    """(pointer array, length array, n, object to keep alive) for a list of bytes or a PinnedFiles."""
+    if isinstance(files, PinnedFiles):
+        n = len(files)
+        return (C.c_void_p * n)(*files.ptrs), (C.c_size_t * n)(*files.lens), n, files
+    n = len(files)
+    keep = [C.c_char_p(f) for f in files]
+    ptrs = (C.c_void_p * n)(*[C.cast(k, C.c_void_p).value for k in keep])
+    return ptrs, (C.c_size_t * n)(*[len(f) for f in files]), n, (keep, files)
+
+
 class Batch:
     """mj_batch: n JPEG files parsed, laid out and resident in HBM."""
 
     def __init__(self, ctx, files, flags=0):
         self.ctx = ctx
         self.lib = ctx.lib
-        n = len(files)
-        bufs = (C.c_char_p * n)(*files)
-        lens = (C.c_size_t * n)(*[len(f) for f in files])
+        ptrs, lens, n, keep = _file_args(files)
         self.h = C.c_void_p()
-        _check(self.lib, self.lib.mj_batch_create(ctx.h, bufs, lens, n, flags, C.byref(self.h)), "mj_batch_create")
+        self.owned = True
+        _check(self.lib, self.lib.mj_batch_create(ctx.h, C.cast(ptrs, C.POINTER(C.c_char_p)), lens, n, flags, C.byref(self.h)),
+               "mj_batch_create")
         self.n = n
         self.flags = flags
         ctx._batches.add(self)
+
+    @classmethod
+    def _view(cls, ctx, handle, n, flags, keep):
+        """A batch owned by the library (a pipeline slot): never destroyed from here."""
+        self = cls.__new__(cls)
+        self.ctx, self.lib, self.h, self.n, self.flags, self.owned, self._keep = ctx, ctx.lib, handle, n, flags, False, keep
+        return self
 
     def decode(self):
         _check(self.lib, self.lib.mj_batch_decode(self.h), "mj_batch_decode")
@@ -198,7 +264,38 @@ class Batch:
 
     def close(self):
         if self.h:
-            self.lib.mj_batch_destroy(self.h)
+            if self.owned:
+                self.lib.mj_batch_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Pipe:
+    """mj_pipe: batches submitted one after the other; the host work and the copy of one
+    overlap the decode of the one before."""
+
+    def __init__(self, ctx, depth=2, flags=0):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        self.flags = flags
+        self.h = C.c_void_p()
+        _check(self.lib, self.lib.mj_pipe_create(ctx.h, depth, flags, C.byref(self.h)), "mj_pipe_create")
+        ctx._batches.add(self)
+
+    def submit(self, files):
+        ptrs, lens, n, keep = _file_args(files)
+        out = C.c_void_p()
+        _check(self.lib, self.lib.mj_pipe_submit(self.h, ptrs, lens, n, C.byref(out)), "mj_pipe_submit")
+        return Batch._view(self.ctx, out, n, self.flags, keep)
+
+    def close(self):
+        if self.h:
+            self.lib.mj_pipe_destroy(self.h)
             self.h = C.c_void_p()
 
     def __del__(self):

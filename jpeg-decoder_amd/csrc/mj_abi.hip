@@ -1,8 +1,20 @@
 /*
  * mj_abi.hip -- the C ABI declared in include/mi355jpeg.h: device context, batch
- * layout in HBM, stage launches, result copies and HIP-event timing.  Host code in
- * the reference's language (C) calls only these entry points; nothing HIP-specific
+ * layout in HBM, uploads, stage launches, result copies and HIP-event timing.  Host code
+ * in the reference's language (C) calls only these entry points; nothing HIP-specific
  * appears in their signatures.
+ *
+ * A batch's device memory is four regions:
+ *   meta   what the host computes per batch (image descriptors, Huffman sets, workgroup
+ *          -> image maps); mirrored byte for byte in page-locked host memory and sent
+ *          with one asynchronous copy;
+ *   state  small device-written tables (tile counts, interval and sequence tables,
+ *          counters); cleared with one asynchronous memset per upload;
+ *   work   the entropy-coded bytes, the unstuffed streams and the subsequence records;
+ *          never cleared: every kernel writes what a later one reads;
+ *   out    coefficients, RGB and optional planes.
+ * mj_batch_create and the pipeline put all four in one allocation per batch (or
+ * pipeline slot).
  */
 #include <hip/hip_runtime.h>
 
@@ -47,21 +59,46 @@ struct EventSet {
 };
 constexpr int kSlotOf[MJ_T_COUNT] = {MJ_T_MEMSET, MJ_T_SCAN, MJ_T_ENTROPY, MJ_T_ENTROPY_FIX, MJ_T_IDCT_COLOUR};
 
+/* offsets of every device buffer inside its region (all multiples of 256) */
+struct Offsets {
+    /* meta */
+    size_t img, sets, tile_img, wg_img, idct_img, idct_first, meta_bytes;
+    /* state */
+    size_t dyn, tile_cnt, tile_base, ivl_start, ivl_seq, seq_ivl, seq_sub, seq_entry, seq_seen, seq_flag, multi, multi_count,
+        stats, state_bytes;
+    /* work */
+    size_t raw, cmp, rec, work_bytes;
+    /* out */
+    size_t coefs, rgb, planes, out_bytes;
+};
+
+struct Carve {
+    size_t off = 0;
+    size_t take(uint64_t bytes) {
+        const size_t o = off;
+        off += (size_t) align_up(bytes ? bytes : 16, 256);
+        return o;
+    }
+};
+
 }  // namespace
 
 struct mj_ctx {
     int device;
-    hipStream_t own;
-    hipStream_t stream;
-    /* page-locked staging for the entropy-coded bytes of the batch being built: the copy to
-     * HBM then runs at the bus rate; kept and grown from one batch to the next */
+    hipStream_t own;      /* the context's compute stream */
+    hipStream_t copy;     /* uploads */
+    hipStream_t stream;   /* where decodes are enqueued: own, or the caller's (mj_set_stream) */
+    /* page-locked staging for entropy-coded bytes handed over in pageable memory and for
+     * result read-back; kept and grown from one batch to the next */
     uint8_t *stage = nullptr;
     size_t stage_cap = 0;
-    /* the device memory of the last batch destroyed, for the next one to move into: a
-     * batch is one allocation, and a caller that decodes batch after batch (or image after
-     * image through the drop-in entry points) allocates once */
+    /* the device memory and the page-locked meta mirror of the last batch destroyed, for the
+     * next one to move into: a caller that decodes batch after batch (or image after image
+     * through the drop-in entry points) allocates once */
     void *arena = nullptr;
     size_t arena_cap = 0;
+    uint8_t *meta_host = nullptr;
+    size_t meta_cap = 0;
 };
 
 struct mj_batch {
@@ -70,58 +107,59 @@ struct mj_batch {
     std::vector<MjImageDev> img;
     std::vector<mj_image_info> info;
     std::vector<MjHuffSet> sets;
-    uint8_t *arena = nullptr;      /* every device buffer of the batch is a piece of this one allocation */
-    size_t arena_cap = 0, arena_used = 0;
-    bool measuring = false;        /* first pass over the buffer list: sizes only */
+    std::vector<uint32_t> tile_img, wg_img, idct_img, idct_first;
+    Offsets o{};
+    uint64_t raw_bytes = 0;
+    uint8_t *arena = nullptr;      /* meta | state | work | out, one allocation */
+    size_t arena_cap = 0;
+    uint8_t *meta_host = nullptr;  /* page-locked mirror of the meta region */
+    size_t meta_cap = 0;
+    uint8_t *stage = nullptr;      /* pipeline slots: own staging for pageable input (a one-shot batch uses the context's) */
+    size_t stage_cap = 0;
     MjDeviceBatch d{};
     uint64_t coef_bytes = 0, rgb_bytes = 0, plane_bytes = 0;
+    hipStream_t stream = nullptr;  /* the stream the last decode was enqueued on */
+    hipEvent_t ev_up = nullptr, ev_done = nullptr;
+    bool uploaded_async = false;   /* ev_up is pending on the copy stream */
+    bool decoded = false;          /* ev_done has been recorded */
     std::vector<EventSet> pending, pool;
     float ms[MJ_T_COUNT] = {0};
     int launches[MJ_T_COUNT] = {0};
 };
 
+struct mj_pipe {
+    mj_ctx *ctx = nullptr;
+    uint32_t flags = 0;
+    std::vector<mj_batch *> slots;
+    uint64_t next = 0;
+};
+
+/* One image ready for placement: flattened descriptor + tables + its entropy bytes. */
+struct MjPrepared {
+    MjImageDev im;
+    MjHuffSet set;
+    const uint8_t *ent;
+};
+
 namespace {
 
-/* the context's page-locked staging buffer, at least `bytes` long (contents are not kept) */
-int stage_reserve(mj_ctx *ctx, size_t bytes) {
-    if (ctx->stage_cap >= bytes) return 0;
-    if (ctx->stage) (void) hipHostFree(ctx->stage);
-    ctx->stage = nullptr;
-    ctx->stage_cap = 0;
-    const size_t cap = bytes + bytes / 4;
-    if (hipHostMalloc(reinterpret_cast<void **>(&ctx->stage), cap, hipHostMallocDefault) != hipSuccess) {
-        return set_err("cannot allocate %zu bytes of page-locked staging memory", cap);
+int host_reserve(uint8_t **buf, size_t *cap, size_t bytes, const char *what) {
+    if (*cap >= bytes) return 0;
+    if (*buf) (void) hipHostFree(*buf);
+    *buf = nullptr;
+    *cap = 0;
+    const size_t want = bytes + bytes / 4;
+    if (hipHostMalloc(reinterpret_cast<void **>(buf), want, hipHostMallocDefault) != hipSuccess) {
+        *buf = nullptr;
+        return set_err("cannot allocate %zu bytes of page-locked memory for %s", want, what);
     }
-    ctx->stage_cap = cap;
-    return 0;
-}
-
-template <typename T>
-int dev_alloc(mj_batch *b, T **out, uint64_t count) {
-    uint64_t bytes = count * sizeof(T);
-    if (bytes == 0) bytes = 16;
-    bytes = align_up(bytes, 256);
-    *out = nullptr;
-    if (!b->measuring) {
-        if (b->arena_used + bytes > b->arena_cap) return set_err("mj_batch_create: internal error: arena too small");
-        *out = reinterpret_cast<T *>(b->arena + b->arena_used);
-    }
-    b->arena_used += bytes;
-    return 0;
-}
-
-template <typename T>
-int dev_upload(mj_batch *b, const T **out, const std::vector<T> &v) {
-    T *p = nullptr;
-    if (dev_alloc(b, &p, v.size())) return -1;
-    if (p && !v.empty()) HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
-    *out = p;
+    *cap = want;
     return 0;
 }
 
 int collect_timing(mj_batch *b) {
     if (b->pending.empty()) return 0;
-    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    if (b->stream) HIP_TRY(hipStreamSynchronize(b->stream));
     for (EventSet &es : b->pending) {
         for (int t = 0; t < MJ_T_COUNT; t++) {
             float ms = 0.f;
@@ -135,148 +173,69 @@ int collect_timing(mj_batch *b) {
     return 0;
 }
 
-}  // namespace
-
-extern "C" {
-
-const char *mj_last_error(void) {
-    return g_err;
+mj_batch *batch_new(mj_ctx *ctx) {
+    mj_batch *b = new mj_batch();
+    b->ctx = ctx;
+    if (hipEventCreateWithFlags(&b->ev_up, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&b->ev_done, hipEventDisableTiming) != hipSuccess) {
+        if (b->ev_up) (void) hipEventDestroy(b->ev_up);
+        delete b;
+        set_err("cannot create HIP events");
+        return nullptr;
+    }
+    return b;
 }
 
-int mj_create(int device, mj_ctx **out) {
-    if (!out) return set_err("mj_create: null output");
-    int n = 0;
-    hipError_t e = hipGetDeviceCount(&n);
-    if (e != hipSuccess || n <= 0) {
-        return set_err("mj_create: no HIP device available (%s); this library has no CPU decode path",
-                       e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+/* wait for everything enqueued for the batch: its upload and its last decode */
+int batch_wait(mj_batch *b) {
+    if (b->uploaded_async) {
+        HIP_TRY(hipEventSynchronize(b->ev_up));
+        b->uploaded_async = false;
     }
-    if (device < 0 || device >= n) return set_err("mj_create: device %d out of range (0..%d)", device, n - 1);
-    HIP_TRY(hipSetDevice(device));
-    mj_ctx *c = new mj_ctx();
-    c->device = device;
-    e = hipStreamCreateWithFlags(&c->own, hipStreamNonBlocking);
-    if (e != hipSuccess) {
-        delete c;
-        return set_err("mj_create: hipStreamCreate failed: %s", hipGetErrorString(e));
-    }
-    c->stream = c->own;
-    *out = c;
+    if (b->decoded) HIP_TRY(hipEventSynchronize(b->ev_done));
     return 0;
 }
 
-void mj_destroy(mj_ctx *ctx) {
-    if (!ctx) return;
-    (void) hipSetDevice(ctx->device);
-    (void) hipStreamSynchronize(ctx->stream);
-    (void) hipStreamDestroy(ctx->own);
-    if (ctx->stage) (void) hipHostFree(ctx->stage);
-    if (ctx->arena) (void) hipFree(ctx->arena);
-    delete ctx;
-}
-
-int mj_set_stream(mj_ctx *ctx, void *hip_stream) {
-    if (!ctx) return set_err("mj_set_stream: null context");
-    ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own;
-    return 0;
-}
-
-void mj_batch_destroy(mj_batch *b) {
-    if (!b) return;
-    (void) hipSetDevice(b->ctx->device);
-    (void) hipStreamSynchronize(b->ctx->stream);
-    for (EventSet &es : b->pending) b->pool.push_back(es);
-    for (EventSet &es : b->pool) {
-        for (hipEvent_t ev : es.ev) (void) hipEventDestroy(ev);
-    }
-    if (b->arena) {
-        mj_ctx *c = b->ctx;
-        if (c->arena && c->arena_cap < b->arena_cap) {
-            (void) hipFree(c->arena);
-            c->arena = nullptr;
-        }
-        if (!c->arena) {
-            c->arena = b->arena;
-            c->arena_cap = b->arena_cap;
-        } else {
-            (void) hipFree(b->arena);
-        }
-    }
-    delete b;
-}
-
-/* One image ready for placement: flattened descriptor + tables + its entropy bytes. */
-struct MjPrepared {
-    MjImageDev im;
-    MjHuffSet set;
-    const uint8_t *ent;
-};
-
-static int batch_build(mj_ctx *ctx, std::vector<MjPrepared> &prep, uint32_t flags, mj_batch **out);
-
-int mj_batch_create(mj_ctx *ctx, const uint8_t *const *bufs, const size_t *lens, int n, uint32_t flags,
-                    mj_batch **out) {
-    if (!ctx || !bufs || !lens || !out || n <= 0) return set_err("mj_batch_create: bad arguments");
-    std::vector<MjPrepared> prep(n);
+/* host: headers -> descriptors (decode.c:160-415 marker walk + table flattening) */
+int prepare(const uint8_t *const *bufs, const size_t *lens, int n, std::vector<MjPrepared> &prep, const char *who) {
+    prep.resize(n);
     for (int i = 0; i < n; i++) {
         MjParsed P;
         const char *why = "?";
+        if (!bufs[i]) return set_err("%s: image %d: null buffer", who, i);
         if (mj_parse_headers(bufs[i], lens[i], &P, &why) != 0) {
-            mj_parsed_free(&P);
-            return set_err("mj_batch_create: image %d: %s", i, why);
+            return set_err("%s: image %d: %s", who, i, why);   /* the parser freed what it had */
         }
         if (mj_flatten_image(&P, lens[i], &prep[i].im, &prep[i].set, &why) != 0) {
             mj_parsed_free(&P);
-            return set_err("mj_batch_create: image %d: %s", i, why);
+            return set_err("%s: image %d: %s", who, i, why);
         }
         prep[i].ent = bufs[i] + P.ent_pos;
         mj_parsed_free(&P);
     }
-    return batch_build(ctx, prep, flags, out);
+    return 0;
 }
 
-int mj_batch_create_scan(mj_ctx *ctx, const uint8_t *entropy, size_t entropy_len, const FrameHeader *fh,
-                         const ScanHeader *sh, const HuffTables *hts, const QuantTables *qts, RestartInterval ri,
-                         uint32_t flags, mj_batch **out) {
-    if (!ctx || !entropy || !fh || !sh || !hts || !qts || !out) return set_err("mj_batch_create_scan: bad arguments");
-    MjParsed P;
-    memset(&P, 0, sizeof P);
-    P.fh = *fh;   /* shallow views: nothing here is freed through P */
-    P.sh = *sh;
-    P.hts = *hts;
-    P.qts = *qts;
-    P.ri = ri;
-    P.ent_pos = 0;
-    std::vector<MjPrepared> prep(1);
-    const char *why = "?";
-    if (mj_flatten_image(&P, entropy_len, &prep[0].im, &prep[0].set, &why) != 0) {
-        return set_err("mj_batch_create_scan: %s", why);
-    }
-    prep[0].ent = entropy;
-    return batch_build(ctx, prep, flags, out);
-}
-
-static int batch_build(mj_ctx *ctx, std::vector<MjPrepared> &prep, uint32_t flags, mj_batch **out) {
+/* host: where every image and every table goes; no HIP call */
+int layout(mj_batch *b, const std::vector<MjPrepared> &prep, uint32_t flags) {
     const int n = (int) prep.size();
-    HIP_TRY(hipSetDevice(ctx->device));
-    mj_batch *b = new mj_batch();
-    b->ctx = ctx;
     b->flags = flags;
     b->img.resize(n);
     b->info.resize(n);
+    b->sets.clear();
+    b->tile_img.clear();
+    b->wg_img.clear();
+    b->idct_img.clear();
+    b->idct_first.assign(n, 0);
 
     uint64_t raw_total = 0, cmp_total = 0, coef_blocks = 0, rgb_total = 0, plane_total = 0;
     uint64_t n_tiles = 0, n_ivl = 0, n_seq = 0, n_rec = 0, n_wg = 0, n_multi = 0, n_idct = 0;
-    std::vector<uint32_t> tile_img, wg_img, idct_img, idct_first(n);
-
     for (int i = 0; i < n; i++) {
         MjImageDev &im = b->img[i];
         im = prep[i].im;
         const MjHuffSet &set = prep[i].set;
         if (im.raw_len >= (1ull << 28)) {
-            mj_batch_destroy(b);
-            return set_err("mj_batch_create: image %d: entropy segment of %llu bytes is too large", i,
-                           (unsigned long long) im.raw_len);
+            return set_err("image %d: entropy segment of %llu bytes is too large", i, (unsigned long long) im.raw_len);
         }
         /* images with identical tables share one set */
         uint32_t si = 0;
@@ -318,14 +277,13 @@ static int batch_build(mj_ctx *ctx, std::vector<MjPrepared> &prep, uint32_t flag
         im.multi_cap = (uint32_t) (mc < im.n_ivl ? mc : im.n_ivl);
         n_multi += im.multi_cap;
         const uint32_t iw = im.mcus_y * mj_idct_tiles_x(im.mcus_x, im.bpm, im.hmax);
-        idct_first[i] = (uint32_t) n_idct;
+        b->idct_first[i] = (uint32_t) n_idct;
         n_idct += iw;
-        tile_img.insert(tile_img.end(), im.n_tiles, (uint32_t) i);
-        wg_img.insert(wg_img.end(), wgs, (uint32_t) i);
-        idct_img.insert(idct_img.end(), iw, (uint32_t) i);
+        b->tile_img.insert(b->tile_img.end(), im.n_tiles, (uint32_t) i);
+        b->wg_img.insert(b->wg_img.end(), wgs, (uint32_t) i);
+        b->idct_img.insert(b->idct_img.end(), iw, (uint32_t) i);
         if (n_tiles >= (1ull << 31) || n_seq >= (1ull << 31) || n_rec >= (1ull << 31) || n_idct >= (1ull << 31) || n_ivl >= (1ull << 31)) {
-            mj_batch_destroy(b);
-            return set_err("mj_batch_create: batch too large");
+            return set_err("batch too large");
         }
 
         mj_image_info &inf = b->info[i];
@@ -352,6 +310,7 @@ static int batch_build(mj_ctx *ctx, std::vector<MjPrepared> &prep, uint32_t flag
     }
 
     MjDeviceBatch &d = b->d;
+    memset(&d, 0, sizeof d);
     d.n_img = (uint32_t) n;
     d.n_tiles = (uint32_t) n_tiles;
     d.n_entropy_wg = (uint32_t) n_wg;
@@ -359,7 +318,11 @@ static int batch_build(mj_ctx *ctx, std::vector<MjPrepared> &prep, uint32_t flag
     d.n_idct_wg = (uint32_t) n_idct;
     d.want_planes = (flags & MJ_WANT_PLANES) ? 1u : 0u;
     d.rgba = (flags & MJ_OUT_RGBA) ? 1u : 0u;
+#if defined(MJ_EXPERIMENT)
     d.dbg = (flags >> 16) & 0xFFFFu;
+#else
+    d.dbg = 0;
+#endif
     d.max_ntab = 1;
     d.max_nac = 1;
     for (const MjHuffSet &hs : b->sets) {
@@ -368,100 +331,149 @@ static int batch_build(mj_ctx *ctx, std::vector<MjPrepared> &prep, uint32_t flag
     }
     b->coef_bytes = coef_blocks * 128;
     b->rgb_bytes = rgb_total;
-    b->plane_bytes = plane_total;
+    b->plane_bytes = d.want_planes ? plane_total : 0;
+    b->raw_bytes = raw_total + 64;
 
-    /* raw entropy bytes: staged on the host, one copy to HBM */
-    const size_t raw_bytes = (size_t) raw_total + 64;
-    if (stage_reserve(ctx, raw_bytes)) {
-        mj_batch_destroy(b);
-        return -1;
-    }
-    {
-        uint8_t *raw = ctx->stage;
-        uint64_t at = 0;
-        for (int i = 0; i < n; i++) {       /* the images' bytes, zeros in the padding between them */
-            const MjImageDev &im = b->img[i];
-            memset(raw + at, 0, (size_t) (im.raw_off - at));
-            memcpy(raw + im.raw_off, prep[i].ent, im.raw_len);
-            at = im.raw_off + im.raw_len;
-        }
-        memset(raw + at, 0, raw_bytes - (size_t) at);
-    }
-
-    /* the buffer list runs twice: once to add up the sizes, once to hand out the pieces */
-    auto place = [&]() -> int {
-        int rc = 0;
-        rc |= dev_upload(b, &d.img, b->img);
-        rc |= dev_upload(b, &d.sets, b->sets);
-        {
-            uint8_t *p = nullptr;
-            rc |= dev_alloc(b, &p, raw_bytes);
-            if (!rc && p && hipMemcpy(p, ctx->stage, raw_bytes, hipMemcpyHostToDevice) != hipSuccess) rc = -1;
-            d.raw = p;
-        }
-        rc |= dev_upload(b, &d.tile_img, tile_img);
-        rc |= dev_upload(b, &d.wg_img, wg_img);
-        rc |= dev_upload(b, &d.idct_wg_img, idct_img);
-        rc |= dev_upload(b, &d.idct_wg_first, idct_first);
-        rc |= dev_alloc(b, &d.dyn, (uint64_t) n);
-        rc |= dev_alloc(b, &d.cmp, cmp_total + 64);
-        rc |= dev_alloc(b, &d.tile_cnt, n_tiles);
-        rc |= dev_alloc(b, &d.tile_base, n_tiles);
-        rc |= dev_alloc(b, &d.ivl_start, n_ivl);
-        rc |= dev_alloc(b, &d.ivl_seq, n_ivl);
-        rc |= dev_alloc(b, &d.seq_ivl, n_seq);
-        rc |= dev_alloc(b, &d.seq_sub, n_seq);
-        rc |= dev_alloc(b, &d.rec, n_rec);
-        rc |= dev_alloc(b, &d.seq_entry, n_seq);
-        rc |= dev_alloc(b, &d.seq_seen, n_seq);
-        rc |= dev_alloc(b, &d.seq_flag, n_seq);
-        rc |= dev_alloc(b, &d.multi, n_multi);
-        rc |= dev_alloc(b, &d.multi_count, 4);
-        rc |= dev_alloc(b, &d.coefs, coef_blocks * 64);
-        rc |= dev_alloc(b, &d.rgb, rgb_total);
-        rc |= dev_alloc(b, &d.planes, d.want_planes ? plane_total : 0);
-        rc |= dev_alloc(b, &d.stats, (uint64_t) MJ_ST_COUNT);
-        return rc;
-    };
-    b->measuring = true;
-    b->arena_used = 0;
-    int rc = place();
-    if (!rc) {
-        const size_t need = b->arena_used;
-        if (ctx->arena && ctx->arena_cap >= need) {          /* move into what the last batch left */
-            b->arena = static_cast<uint8_t *>(ctx->arena);
-            b->arena_cap = ctx->arena_cap;
-            ctx->arena = nullptr;
-            ctx->arena_cap = 0;
-        } else {
-            if (ctx->arena) {
-                (void) hipFree(ctx->arena);
-                ctx->arena = nullptr;
-                ctx->arena_cap = 0;
-            }
-            void *p = nullptr;
-            if (hipMalloc(&p, need) != hipSuccess) {
-                mj_batch_destroy(b);
-                return set_err("mj_batch_create: cannot allocate %zu bytes of device memory", need);
-            }
-            b->arena = static_cast<uint8_t *>(p);
-            b->arena_cap = need;
-        }
-        /* everything starts at zero, whoever used the memory before */
-        if (hipMemset(b->arena, 0, need) != hipSuccess) rc = -1;
-        b->measuring = false;
-        b->arena_used = 0;
-        if (!rc) rc = place();
-    }
-    if (rc) {
-        mj_batch_destroy(b);
-        return -1;
-    }
-    *out = b;
+    Offsets &o = b->o;
+    Carve m, st, w, out;
+    o.img = m.take((uint64_t) n * sizeof(MjImageDev));
+    o.sets = m.take(b->sets.size() * sizeof(MjHuffSet));
+    o.tile_img = m.take(n_tiles * 4);
+    o.wg_img = m.take(n_wg * 4);
+    o.idct_img = m.take(n_idct * 4);
+    o.idct_first = m.take((uint64_t) n * 4);
+    o.meta_bytes = m.off;
+    o.dyn = st.take((uint64_t) n * sizeof(MjImageDyn));
+    o.tile_cnt = st.take(n_tiles * sizeof(MjTileCnt));
+    o.tile_base = st.take(n_tiles * sizeof(MjTileBase));
+    o.ivl_start = st.take(n_ivl * 4);
+    o.ivl_seq = st.take(n_ivl * 4);
+    o.seq_ivl = st.take(n_seq * 4);
+    o.seq_sub = st.take(n_seq * 4);
+    o.seq_entry = st.take(n_seq * sizeof(MjSeqEntry));
+    o.seq_seen = st.take(n_seq * sizeof(MjState));
+    o.seq_flag = st.take(n_seq * 4);
+    o.multi = st.take(n_multi * sizeof(uint2));
+    o.multi_count = st.take(16);
+    o.stats = st.take(MJ_ST_COUNT * sizeof(unsigned long long));
+    o.state_bytes = st.off;
+    o.raw = w.take(b->raw_bytes);
+    o.cmp = w.take(cmp_total + 64);
+    o.rec = w.take(n_rec * sizeof(MjSubRec));
+    o.work_bytes = w.off;
+    o.coefs = out.take(b->coef_bytes);
+    o.rgb = out.take(rgb_total);
+    o.planes = out.take(b->plane_bytes);
+    o.out_bytes = out.off;
     return 0;
 }
 
-static int take_events(mj_batch *b, EventSet *es) {
+/* device pointers of every buffer, given where the regions live */
+void bind(mj_batch *b, uint8_t *meta, uint8_t *state, uint8_t *work, uint8_t *coefs, uint8_t *rgb, uint8_t *planes) {
+    const Offsets &o = b->o;
+    MjDeviceBatch &d = b->d;
+    d.img = reinterpret_cast<const MjImageDev *>(meta + o.img);
+    d.sets = reinterpret_cast<const MjHuffSet *>(meta + o.sets);
+    d.tile_img = reinterpret_cast<const uint32_t *>(meta + o.tile_img);
+    d.wg_img = reinterpret_cast<const uint32_t *>(meta + o.wg_img);
+    d.idct_wg_img = reinterpret_cast<const uint32_t *>(meta + o.idct_img);
+    d.idct_wg_first = reinterpret_cast<const uint32_t *>(meta + o.idct_first);
+    d.dyn = reinterpret_cast<MjImageDyn *>(state + o.dyn);
+    d.tile_cnt = reinterpret_cast<MjTileCnt *>(state + o.tile_cnt);
+    d.tile_base = reinterpret_cast<MjTileBase *>(state + o.tile_base);
+    d.ivl_start = reinterpret_cast<uint32_t *>(state + o.ivl_start);
+    d.ivl_seq = reinterpret_cast<uint32_t *>(state + o.ivl_seq);
+    d.seq_ivl = reinterpret_cast<uint32_t *>(state + o.seq_ivl);
+    d.seq_sub = reinterpret_cast<uint32_t *>(state + o.seq_sub);
+    d.seq_entry = reinterpret_cast<MjSeqEntry *>(state + o.seq_entry);
+    d.seq_seen = reinterpret_cast<MjState *>(state + o.seq_seen);
+    d.seq_flag = reinterpret_cast<uint32_t *>(state + o.seq_flag);
+    d.multi = reinterpret_cast<uint2 *>(state + o.multi);
+    d.multi_count = reinterpret_cast<uint32_t *>(state + o.multi_count);
+    d.stats = reinterpret_cast<unsigned long long *>(state + o.stats);
+    d.raw = work + o.raw;
+    d.cmp = work + o.cmp;
+    d.rec = reinterpret_cast<MjSubRec *>(work + o.rec);
+    d.coefs = reinterpret_cast<int16_t *>(coefs);
+    d.rgb = rgb;
+    d.planes = planes;
+}
+
+/* the batch's own allocation: take over what is there if it is large enough */
+int arena_reserve(mj_batch *b, size_t need) {
+    mj_ctx *ctx = b->ctx;
+    if (b->arena && b->arena_cap >= need) return 0;
+    if (b->arena) {
+        (void) hipFree(b->arena);
+        b->arena = nullptr;
+        b->arena_cap = 0;
+    }
+    if (ctx->arena && ctx->arena_cap >= need) {          /* move into what the last batch left */
+        b->arena = static_cast<uint8_t *>(ctx->arena);
+        b->arena_cap = ctx->arena_cap;
+        ctx->arena = nullptr;
+        ctx->arena_cap = 0;
+        return 0;
+    }
+    if (ctx->arena) {
+        (void) hipFree(ctx->arena);
+        ctx->arena = nullptr;
+        ctx->arena_cap = 0;
+    }
+    void *p = nullptr;
+    if (hipMalloc(&p, need) != hipSuccess) return set_err("cannot allocate %zu bytes of device memory", need);
+    b->arena = static_cast<uint8_t *>(p);
+    b->arena_cap = need;
+    return 0;
+}
+
+bool is_page_locked(const void *p) {
+    hipPointerAttribute_t a;
+    memset(&a, 0, sizeof a);
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void) hipGetLastError();
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
+
+bool all_page_locked(const std::vector<MjPrepared> &prep) {
+    for (const MjPrepared &p : prep) {
+        if (!is_page_locked(p.ent)) return false;
+    }
+    return true;
+}
+
+/* Enqueue on `s`: clear the state region, send the meta region and the entropy-coded
+ * bytes.  meta/state: device addresses of the regions.  With stage == nullptr every
+ * image's bytes go straight from the caller's memory, one copy per image; otherwise they
+ * are gathered in `stage` (page-locked, at least raw_bytes) first and leave as one copy.
+ * Allocates nothing. */
+int upload(mj_batch *b, const std::vector<MjPrepared> &prep, uint8_t *meta, uint8_t *state, uint8_t *stage, hipStream_t s) {
+    const Offsets &o = b->o;
+    HIP_TRY(hipMemsetAsync(state, 0, o.state_bytes, s));
+    uint8_t *mh = b->meta_host;
+    const size_t n = b->img.size();
+    memcpy(mh + o.img, b->img.data(), n * sizeof(MjImageDev));
+    memcpy(mh + o.sets, b->sets.data(), b->sets.size() * sizeof(MjHuffSet));
+    memcpy(mh + o.tile_img, b->tile_img.data(), b->tile_img.size() * 4);
+    memcpy(mh + o.wg_img, b->wg_img.data(), b->wg_img.size() * 4);
+    memcpy(mh + o.idct_img, b->idct_img.data(), b->idct_img.size() * 4);
+    memcpy(mh + o.idct_first, b->idct_first.data(), n * 4);
+    HIP_TRY(hipMemcpyAsync(meta, mh, o.meta_bytes, hipMemcpyHostToDevice, s));
+    uint8_t *raw = const_cast<uint8_t *>(b->d.raw);
+    if (stage) {
+        for (size_t i = 0; i < n; i++) memcpy(stage + b->img[i].raw_off, prep[i].ent, b->img[i].raw_len);
+        HIP_TRY(hipMemcpyAsync(raw, stage, b->raw_bytes, hipMemcpyHostToDevice, s));
+    } else {
+        for (size_t i = 0; i < n; i++) {
+            if (b->img[i].raw_len) HIP_TRY(hipMemcpyAsync(raw + b->img[i].raw_off, prep[i].ent, b->img[i].raw_len, hipMemcpyHostToDevice, s));
+        }
+    }
+    return 0;
+}
+
+int take_events(mj_batch *b, EventSet *es) {
     if (!b->pool.empty()) {
         *es = b->pool.back();
         b->pool.pop_back();
@@ -471,10 +483,8 @@ static int take_events(mj_batch *b, EventSet *es) {
     return 0;
 }
 
-int mj_batch_decode(mj_batch *b) {
-    if (!b) return set_err("mj_batch_decode: null batch");
-    HIP_TRY(hipSetDevice(b->ctx->device));
-    hipStream_t s = b->ctx->stream;
+/* the whole hot path of the batch on stream s (asynchronous) */
+int enqueue_decode(mj_batch *b, hipStream_t s) {
     const bool timing = (b->flags & MJ_TIMING) != 0;
     EventSet es{};
     if (timing) {
@@ -482,6 +492,8 @@ int mj_batch_decode(mj_batch *b) {
         if (take_events(b, &es)) return -1;
     }
     auto mark = [&](int i) -> hipError_t { return timing ? hipEventRecord(es.ev[i], s) : hipSuccess; };
+    b->stream = s;
+    if (b->uploaded_async) HIP_TRY(hipStreamWaitEvent(s, b->ev_up, 0));
 
     HIP_TRY(mark(0));
     HIP_TRY(hipMemsetAsync(b->d.stats, 0, MJ_ST_COUNT * sizeof(unsigned long long), s));
@@ -506,16 +518,280 @@ int mj_batch_decode(mj_batch *b) {
     }
     HIP_TRY(mj_launch_idct_colour(b->d, s));
     HIP_TRY(mark(5));
+    HIP_TRY(hipEventRecord(b->ev_done, s));
+    b->decoded = true;
     if (timing) b->pending.push_back(es);
     return 0;
+}
+
+void batch_free(mj_batch *b, bool park) {
+    for (EventSet &es : b->pending) b->pool.push_back(es);
+    for (EventSet &es : b->pool) {
+        for (hipEvent_t ev : es.ev) (void) hipEventDestroy(ev);
+    }
+    mj_ctx *c = b->ctx;
+    if (b->arena) {
+        if (park && c->arena && c->arena_cap < b->arena_cap) {
+            (void) hipFree(c->arena);
+            c->arena = nullptr;
+        }
+        if (park && !c->arena) {
+            c->arena = b->arena;
+            c->arena_cap = b->arena_cap;
+        } else {
+            (void) hipFree(b->arena);
+        }
+    }
+    if (b->meta_host) {
+        if (park && c->meta_host && c->meta_cap < b->meta_cap) {
+            (void) hipHostFree(c->meta_host);
+            c->meta_host = nullptr;
+        }
+        if (park && !c->meta_host) {
+            c->meta_host = b->meta_host;
+            c->meta_cap = b->meta_cap;
+        } else {
+            (void) hipHostFree(b->meta_host);
+        }
+    }
+    if (b->stage) (void) hipHostFree(b->stage);
+    if (b->ev_up) (void) hipEventDestroy(b->ev_up);
+    if (b->ev_done) (void) hipEventDestroy(b->ev_done);
+    delete b;
+}
+
+/* lay the images out in the batch's own allocation and send them on the copy stream;
+ * with `wait` the call returns when the copies are through (the caller's buffers are
+ * then free) */
+int fill_own(mj_batch *b, const std::vector<MjPrepared> &prep, uint32_t flags, bool own_stage, bool wait) {
+    mj_ctx *ctx = b->ctx;
+    if (layout(b, prep, flags)) return -1;
+    const Offsets &o = b->o;
+    const size_t need = o.meta_bytes + o.state_bytes + o.work_bytes + o.out_bytes;
+    if (arena_reserve(b, need)) return -1;
+    if (!b->meta_host && ctx->meta_host) {               /* the mirror the last batch left */
+        b->meta_host = ctx->meta_host;
+        b->meta_cap = ctx->meta_cap;
+        ctx->meta_host = nullptr;
+        ctx->meta_cap = 0;
+    }
+    if (host_reserve(&b->meta_host, &b->meta_cap, o.meta_bytes, "the batch descriptors")) return -1;
+    uint8_t *meta = b->arena, *state = meta + o.meta_bytes, *work = state + o.state_bytes, *out = work + o.work_bytes;
+    bind(b, meta, state, work, out + o.coefs, out + o.rgb, b->plane_bytes ? out + o.planes : nullptr);
+    uint8_t *stage = nullptr;
+    if (!all_page_locked(prep)) {
+        if (own_stage) {
+            if (host_reserve(&b->stage, &b->stage_cap, b->raw_bytes, "staging the entropy-coded bytes")) return -1;
+            stage = b->stage;
+        } else {
+            if (host_reserve(&ctx->stage, &ctx->stage_cap, b->raw_bytes, "staging the entropy-coded bytes")) return -1;
+            stage = ctx->stage;
+        }
+    }
+    if (upload(b, prep, meta, state, stage, ctx->copy)) return -1;
+    HIP_TRY(hipEventRecord(b->ev_up, ctx->copy));
+    b->uploaded_async = true;
+    b->decoded = false;
+    if (wait) {
+        HIP_TRY(hipEventSynchronize(b->ev_up));
+        b->uploaded_async = false;
+    }
+    return 0;
+}
+
+int check_flags(uint32_t flags, const char *who) {
+#if !defined(MJ_EXPERIMENT)
+    if (flags & ~MJ_FLAGS_ALL) return set_err("%s: unknown flag bits 0x%x", who, flags & ~MJ_FLAGS_ALL);
+#else
+    (void) flags;
+    (void) who;
+#endif
+    return 0;
+}
+
+int batch_build(mj_ctx *ctx, std::vector<MjPrepared> &prep, uint32_t flags, mj_batch **out, const char *who) {
+    if (check_flags(flags, who)) return -1;
+    HIP_TRY(hipSetDevice(ctx->device));
+    mj_batch *b = batch_new(ctx);
+    if (!b) return -1;
+    if (fill_own(b, prep, flags, false, true) != 0) {
+        char msg[sizeof g_err];
+        snprintf(msg, sizeof msg, "%s", g_err);
+        batch_free(b, true);
+        return set_err("%s: %s", who, msg);
+    }
+    *out = b;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *mj_last_error(void) {
+    return g_err;
+}
+
+int mj_create(int device, mj_ctx **out) {
+    if (!out) return set_err("mj_create: null output");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        return set_err("mj_create: no HIP device available (%s); this library has no CPU decode path",
+                       e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    }
+    if (device < 0 || device >= n) return set_err("mj_create: device %d out of range (0..%d)", device, n - 1);
+    HIP_TRY(hipSetDevice(device));
+    mj_ctx *c = new mj_ctx();
+    c->device = device;
+    e = hipStreamCreateWithFlags(&c->own, hipStreamNonBlocking);
+    if (e == hipSuccess) {
+        e = hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking);
+        if (e != hipSuccess) (void) hipStreamDestroy(c->own);
+    }
+    if (e != hipSuccess) {
+        delete c;
+        return set_err("mj_create: hipStreamCreate failed: %s", hipGetErrorString(e));
+    }
+    c->stream = c->own;
+    *out = c;
+    return 0;
+}
+
+void mj_destroy(mj_ctx *ctx) {
+    if (!ctx) return;
+    (void) hipSetDevice(ctx->device);
+    (void) hipStreamSynchronize(ctx->stream);
+    (void) hipStreamSynchronize(ctx->own);
+    (void) hipStreamSynchronize(ctx->copy);
+    (void) hipStreamDestroy(ctx->own);
+    (void) hipStreamDestroy(ctx->copy);
+    if (ctx->stage) (void) hipHostFree(ctx->stage);
+    if (ctx->meta_host) (void) hipHostFree(ctx->meta_host);
+    if (ctx->arena) (void) hipFree(ctx->arena);
+    delete ctx;
+}
+
+int mj_set_stream(mj_ctx *ctx, void *hip_stream) {
+    if (!ctx) return set_err("mj_set_stream: null context");
+    ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own;
+    return 0;
+}
+
+void *mj_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        set_err("mj_host_alloc: cannot allocate %zu bytes of page-locked memory", bytes);
+        return nullptr;
+    }
+    return p;
+}
+
+void mj_host_free(void *p) {
+    if (p) (void) hipHostFree(p);
+}
+
+void mj_batch_destroy(mj_batch *b) {
+    if (!b) return;
+    (void) hipSetDevice(b->ctx->device);
+    /* the stream every decode of this batch went to, whatever the context's current one is */
+    (void) batch_wait(b);
+    if (b->stream) (void) hipStreamSynchronize(b->stream);
+    batch_free(b, true);
+}
+
+int mj_batch_create(mj_ctx *ctx, const uint8_t *const *bufs, const size_t *lens, int n, uint32_t flags,
+                    mj_batch **out) {
+    if (!ctx || !bufs || !lens || !out || n <= 0) return set_err("mj_batch_create: bad arguments");
+    std::vector<MjPrepared> prep;
+    if (prepare(bufs, lens, n, prep, "mj_batch_create")) return -1;
+    return batch_build(ctx, prep, flags, out, "mj_batch_create");
+}
+
+int mj_batch_create_scan(mj_ctx *ctx, const uint8_t *entropy, size_t entropy_len, const FrameHeader *fh,
+                         const ScanHeader *sh, const HuffTables *hts, const QuantTables *qts, RestartInterval ri,
+                         uint32_t flags, mj_batch **out) {
+    if (!ctx || !entropy || !fh || !sh || !hts || !qts || !out) return set_err("mj_batch_create_scan: bad arguments");
+    MjParsed P;
+    memset(&P, 0, sizeof P);
+    P.fh = *fh;   /* shallow views: nothing here is freed through P */
+    P.sh = *sh;
+    P.hts = *hts;
+    P.qts = *qts;
+    P.ri = ri;
+    P.ent_pos = 0;
+    std::vector<MjPrepared> prep(1);
+    const char *why = "?";
+    if (mj_flatten_image(&P, entropy_len, &prep[0].im, &prep[0].set, &why) != 0) {
+        return set_err("mj_batch_create_scan: %s", why);
+    }
+    prep[0].ent = entropy;
+    return batch_build(ctx, prep, flags, out, "mj_batch_create_scan");
+}
+
+int mj_batch_decode(mj_batch *b) {
+    if (!b) return set_err("mj_batch_decode: null batch");
+    HIP_TRY(hipSetDevice(b->ctx->device));
+    return enqueue_decode(b, b->ctx->stream);
 }
 
 int mj_batch_sync(mj_batch *b) {
     if (!b) return set_err("mj_batch_sync: null batch");
     HIP_TRY(hipSetDevice(b->ctx->device));
-    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    return batch_wait(b);
+}
+
+/* ---- pipeline: batch k+1 is parsed and uploaded while batch k decodes ------------ */
+
+int mj_pipe_create(mj_ctx *ctx, int depth, uint32_t flags, mj_pipe **out) {
+    if (!ctx || !out || depth < 2 || depth > 8) return set_err("mj_pipe_create: bad arguments (depth 2..8)");
+    if (check_flags(flags, "mj_pipe_create")) return -1;
+    HIP_TRY(hipSetDevice(ctx->device));
+    mj_pipe *p = new mj_pipe();
+    p->ctx = ctx;
+    p->flags = flags;
+    for (int i = 0; i < depth; i++) {
+        mj_batch *b = batch_new(ctx);
+        if (!b) {
+            for (mj_batch *s : p->slots) batch_free(s, false);
+            delete p;
+            return -1;
+        }
+        p->slots.push_back(b);
+    }
+    *out = p;
     return 0;
 }
+
+void mj_pipe_destroy(mj_pipe *p) {
+    if (!p) return;
+    (void) hipSetDevice(p->ctx->device);
+    for (mj_batch *b : p->slots) {
+        (void) batch_wait(b);
+        if (b->stream) (void) hipStreamSynchronize(b->stream);
+        batch_free(b, false);
+    }
+    delete p;
+}
+
+int mj_pipe_submit(mj_pipe *p, const uint8_t *const *bufs, const size_t *lens, int n, mj_batch **out) {
+    if (!p || !bufs || !lens || !out || n <= 0) return set_err("mj_pipe_submit: bad arguments");
+    mj_ctx *ctx = p->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    mj_batch *b = p->slots[p->next % p->slots.size()];
+    /* the slot's previous occupant: its decode must be over before its memory (device and
+     * page-locked mirrors) is written again */
+    if (batch_wait(b)) return -1;
+    std::vector<MjPrepared> prep;
+    if (prepare(bufs, lens, n, prep, "mj_pipe_submit")) return -1;
+    if (fill_own(b, prep, p->flags, true, false) != 0) return -1;
+    if (enqueue_decode(b, ctx->stream) != 0) return -1;
+    p->next++;
+    *out = b;
+    return 0;
+}
+
+/* ---- results ----------------------------------------------------------------------- */
 
 int mj_batch_size(const mj_batch *b) {
     return b ? (int) b->img.size() : -1;
@@ -563,13 +839,10 @@ int mj_batch_copy_rgb(mj_batch *b, int i, uint8_t *dst, size_t dst_pitch) {
      * pitch on the host (a pitched copy into pageable memory is several times slower) */
     const size_t bytes = (size_t) im.pitch * im.Y;
     if (bytes == 0) return 0;
-    if (stage_reserve(b->ctx, bytes)) return -1;
-    HIP_TRY(hipMemcpy(b->ctx->stage, b->d.rgb + im.rgb_off, bytes, hipMemcpyDeviceToHost));
-    if (dst_pitch == im.pitch) {
-        memcpy(dst, b->ctx->stage, (size_t) im.pitch * (im.Y - 1) + row);
-    } else {
-        for (uint32_t y = 0; y < im.Y; y++) memcpy(dst + (size_t) y * dst_pitch, b->ctx->stage + (size_t) y * im.pitch, row);
-    }
+    mj_ctx *ctx = b->ctx;
+    if (host_reserve(&ctx->stage, &ctx->stage_cap, bytes, "reading results back")) return -1;
+    HIP_TRY(hipMemcpy(ctx->stage, b->d.rgb + im.rgb_off, bytes, hipMemcpyDeviceToHost));
+    for (uint32_t y = 0; y < im.Y; y++) memcpy(dst + (size_t) y * dst_pitch, ctx->stage + (size_t) y * im.pitch, row);
     return 0;
 }
 

@@ -39,7 +39,7 @@ struct MjDeviceBatch {
     uint32_t rgba;           /* 1: four bytes per pixel (R, G, B, 255) */
     uint32_t max_ntab;       /* largest Huffman table set in the batch (sizes the kernels' LDS) */
     uint32_t max_nac;        /* most AC tables in one set */
-    uint32_t dbg;            /* timing experiments only: bit 0 skip write pass, bit 1 skip sync rounds, bit 2 skip coefficient stores */
+    uint32_t dbg;            /* always 0 in the product; see MJ_DBG */
 
     const MjImageDev *img;   /* [n_img] */
     MjImageDyn *dyn;         /* [n_img] */
@@ -67,6 +67,15 @@ struct MjDeviceBatch {
     uint8_t *rgb;
     unsigned long long *stats; /* [MJ_ST_COUNT] */
 };
+
+/* Timing experiments (skip a pass, cap the rounds) exist only in builds with
+ * -DMJ_EXPERIMENT; they produce wrong output by design.  In the product build MJ_DBG is
+ * the constant 0 and the branches disappear. */
+#if defined(MJ_EXPERIMENT)
+#define MJ_DBG(b) ((b).dbg)
+#else
+#define MJ_DBG(b) 0u
+#endif
 
 /* Stage launchers; all asynchronous on `s`.  Return hipSuccess or the launch error. */
 hipError_t mj_launch_scan(const MjDeviceBatch &b, hipStream_t s);

@@ -276,11 +276,11 @@ __global__ __launch_bounds__(SYNC_TPB, 8) void mj_k_entropy_sync(MjDeviceBatch b
     /* rounds: every queued decoder decodes one more subsequence, replaces its record and
      * goes on while the state it reached differs from the one recorded there before */
     uint32_t rounds = 0, tasks = 0;
-    const uint32_t max_rounds = (b.dbg >> 8) & 0xFFu;   /* timing experiments only */
+    const uint32_t max_rounds = (MJ_DBG(b) >> 8) & 0xFFu;
     uint32_t ci = 0;                         /* counter of this round; next is ci + 1, the one to clear ci + 2 (mod 3) */
     for (;;) {
         const uint32_t total = s_cnt[ci];
-        if (total == 0 || (b.dbg & 2u) || (max_rounds && rounds >= max_rounds)) break;
+        if (total == 0 || (MJ_DBG(b) & 2u) || (max_rounds && rounds >= max_rounds)) break;
         /* the number of decoders left never grows, so a wavefront that has none now will
          * get none later: it leaves, and its slot goes to a workgroup still waiting to
          * start (a barrier only counts the wavefronts that are still there) */
@@ -588,7 +588,7 @@ __global__ __launch_bounds__(TPB) void mj_k_entropy_write(MjDeviceBatch b) {
     wave_excl_scan5(nb, d0, d1, d2, d3);
     /* every block of the interval must be accounted for by its last sequence */
     if (first + n == g.nsub && valid && u0 + cnt == n && se.blk + nb + own_nb < blk_end) atomicOr(&b.dyn[ii].status, 1u);
-    if (b.dbg & 1u) return;
+    if (MJ_DBG(b) & 1u) return;
 
     uint32_t k = kc & 0xFFu, c = kc >> 8;
     uint32_t blk = se.blk + nb;
@@ -599,7 +599,7 @@ __global__ __launch_bounds__(TPB) void mj_k_entropy_write(MjDeviceBatch b) {
     uint32_t *list_blk = s_list_blk + wave * 64, *list_lane = s_list_lane + wave * 64;
     const unsigned char *wave_blk = s_blk + wave * 64 * BLK_STRIDE;
     unsigned char *coef_bytes = reinterpret_cast<unsigned char *>(cx.coefs);
-    const uint32_t store_end = (b.dbg & 4u) ? 0u : blk_end;
+    const uint32_t store_end = (MJ_DBG(b) & 4u) ? 0u : blk_end;
 
     MjLane L;
     bool live = valid && mj_write_live(p, k, skip, end, g.b1);
@@ -682,7 +682,11 @@ static size_t table_lds(const MjDeviceBatch &b, uint32_t waves) {
 
 hipError_t mj_launch_entropy(const MjDeviceBatch &b, hipStream_t s) {
     if (b.n_entropy_wg == 0) return hipSuccess;
+#if defined(MJ_EXPERIMENT)
     static const size_t pad = getenv("MJ_TUNE_LDS_PAD") ? (size_t) atol(getenv("MJ_TUNE_LDS_PAD")) : 0;   /* occupancy experiments */
+#else
+    const size_t pad = 0;
+#endif
     const size_t lds = table_lds(b, 0) + SYNC_WAVES * sizeof(SeqGeo) + 4 * sizeof(uint32_t) + SYNC_TPB * sizeof(uint32_t) +
                        (size_t) b.max_nac * sizeof(MjHuffRun) + pad;
     hipLaunchKernelGGL(mj_k_entropy_sync, dim3(b.n_entropy_wg), dim3(SYNC_TPB), lds, s, b);

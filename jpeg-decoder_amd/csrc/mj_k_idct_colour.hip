@@ -350,7 +350,7 @@ __global__ __launch_bounds__(TPB, MJ_IDCT_WAVES) void mj_k_idct_colour(MjDeviceB
     __syncthreads();
 
     /* ---- 2. eight lanes per block, 64 blocks per pass ---------------------- */
-    if (!(b.dbg & 16u)) {
+    if (!(MJ_DBG(b) & 16u)) {
         const uint32_t r = threadIdx.x & 7u;                 /* the lane's row, then column, then row again */
         const uint32_t grp = threadIdx.x >> 3;               /* block within the pass */
         float *tr = reinterpret_cast<float *>(s_tr) + grp * TR_GROUP;
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(TPB, MJ_IDCT_WAVES) void mj_k_idct_colour(MjDeviceB
         }
     }
 
-    if (b.dbg & 8u) return;
+    if (MJ_DBG(b) & 8u) return;
     /* ---- 3. upsample + colour, 4 pixels (12 bytes) per thread per step ----- */
     /* The tile's quads (4 horizontally adjacent pixels) are numbered row-major; a
      * thread takes quad tid, tid + TPB, ... and tracks (row, quad-in-row)

@@ -322,7 +322,23 @@ static uint32_t env_u32(const char *name) {
     return (e && *e) ? (uint32_t) strtoul(e, NULL, 0) : 0u;
 }
 
+/* Tuning overrides of the split (experiments only), read from the environment once per
+ * process, not per image. */
+static struct {
+    int loaded;
+    uint32_t min_lane_bits, lane_subs, sub_bits;
+} g_tune;
+
+static void tune_load(void) {
+    if (__atomic_load_n(&g_tune.loaded, __ATOMIC_ACQUIRE)) return;
+    g_tune.min_lane_bits = env_u32("MJ_TUNE_MIN_LANE_BITS");
+    g_tune.lane_subs = env_u32("MJ_TUNE_LANE_SUBS");
+    g_tune.sub_bits = env_u32("MJ_TUNE_SUB_BITS");
+    __atomic_store_n(&g_tune.loaded, 1, __ATOMIC_RELEASE);
+}
+
 void mj_choose_split(uint64_t raw_len, uint32_t n_ivl, uint32_t *sub_bits, uint32_t *lane_subs) {
+    tune_load();
     uint64_t bits = raw_len * 8;
     uint64_t avg = bits / (n_ivl ? n_ivl : 1);
     uint64_t lane_bits;
@@ -336,7 +352,7 @@ void mj_choose_split(uint64_t raw_len, uint32_t n_ivl, uint32_t *sub_bits, uint3
         lane_bits = (avg + avg / 16 + MJ_SEQ_LANES - 1) / MJ_SEQ_LANES;
         /* short intervals: fewer, longer lanes -- every synchronisation round has a fixed
          * cost, and 256 bits per round is where that stops to dominate */
-        uint32_t minb = env_u32("MJ_TUNE_MIN_LANE_BITS");
+        uint32_t minb = g_tune.min_lane_bits;
         if (!minb) minb = 256;
         if (lane_bits < minb) lane_bits = minb;
         if (lane_bits > 4096) lane_bits = 4096;
@@ -345,10 +361,10 @@ void mj_choose_split(uint64_t raw_len, uint32_t n_ivl, uint32_t *sub_bits, uint3
         g = lane_bits >= 1024 ? 4 : lane_bits >= 512 ? 2 : 1;
     }
     /* tuning overrides (experiments only) */
-    uint32_t t = env_u32("MJ_TUNE_LANE_SUBS");
+    uint32_t t = g_tune.lane_subs;
     if (t >= 1 && t <= MJ_MAX_LANE_SUBS) g = t;
     uint64_t s = (lane_bits + g - 1) / g;
-    t = env_u32("MJ_TUNE_SUB_BITS");
+    t = g_tune.sub_bits;
     if (t) s = t;
     s = (s + 31) / 32 * 32;
     if (s > 32768) s = 32768;
