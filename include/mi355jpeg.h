@@ -115,6 +115,28 @@ int mj_pipe_create(mj_ctx *ctx, int depth, uint32_t flags, mj_pipe **out);
 int mj_pipe_submit(mj_pipe *p, const uint8_t *const *bufs, const size_t *lens, int n, mj_batch **out);
 void mj_pipe_destroy(mj_pipe *p);
 
+/* No counterpart in the reference.  For callers that cannot allocate device memory
+ * (code under HIP graph capture, tight serving loops, harnesses that forbid it):
+ * mj_batch_create + mj_batch_decode in one call that allocates nothing on the device.
+ * The caller passes the files and the two output buffers (device memory, 16-byte
+ * aligned: coefficients as mj_batch_device_coefs describes, RGB as mj_batch_device_rgb);
+ * everything in between -- the entropy-coded bytes, the unstuffed streams, the
+ * subsequence records, the descriptor tables -- lives in a static device array of
+ * MJ_STATIC_SCRATCH_BYTES per GPU, which the library holds from load to process exit.
+ * A batch that needs more (about three times its compressed size plus tables: e.g.
+ * eight 4K images, or one 8K image) is refused with an error; so is any flag but
+ * MJ_OUT_RGBA.  Uploads and kernels are enqueued in order on the context's stream;
+ * the call returns once the uploads are through (bufs[i] may then be released), the
+ * kernels run on.  *view (optional) is the context's own batch object for this call:
+ * valid until the next mj_decode_static or mj_destroy on this context, accepted by
+ * the mj_batch_* accessors (image info, status, sync, copies), ignored by
+ * mj_batch_destroy.  Every call on one GPU uses the same work memory: a call waits
+ * for the previous call of its own context, and calls from different contexts on one
+ * GPU must not overlap -- they would race. */
+#define MJ_STATIC_SCRATCH_BYTES (64u << 20)
+int mj_decode_static(mj_ctx *ctx, const uint8_t *const *bufs, const size_t *lens, int n, uint32_t flags, void *dev_coefs,
+                     size_t coefs_bytes, void *dev_rgb, size_t rgb_bytes, mj_batch **view);
+
 /* Enqueue the whole hot path for the batch on the stream (asynchronous).  Inputs
  * are already resident in HBM; outputs (coefficients, RGB, optional planes) stay
  * in HBM.  May be called repeatedly; every call decodes from scratch. */

@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "mj_batch_decode", "mj_batch_sync", "mj_batch_size", "mj_batch_image_info", "mj_batch_status",
     "mj_batch_device_rgb", "mj_batch_device_coefs", "mj_batch_copy_rgb", "mj_batch_copy_coefs",
     "mj_batch_copy_plane", "mj_batch_kernel_ms", "mj_batch_reset_timing", "mj_batch_entropy_stats",
-    "mj_host_alloc", "mj_host_free", "mj_pipe_create", "mj_pipe_submit", "mj_pipe_destroy",
+    "mj_host_alloc", "mj_host_free", "mj_pipe_create", "mj_pipe_submit", "mj_pipe_destroy", "mj_decode_static",
 ]
 COMPAT_SYMBOLS = [
     "get_byte", "next_byte", "next_bit", "next_bit_size", "check_marker", "next_byte_restart_marker", "progress",
@@ -94,6 +94,8 @@ def load_library():
     lib.mj_pipe_submit.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), i32, C.POINTER(vp)]
     lib.mj_pipe_destroy.argtypes = [vp]
     lib.mj_pipe_destroy.restype = None
+    lib.mj_decode_static.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), i32, u32, vp, C.c_size_t, vp, C.c_size_t,
+                                     C.POINTER(vp)]
     _lib = lib
     return lib
 
@@ -122,6 +124,14 @@ class Context:
     def pipe(self, depth=2, flags=0):
         return Pipe(self, depth, flags)
 
+    def decode_static(self, files, dev_coefs, coefs_bytes, dev_rgb, rgb_bytes, flags=0):
+        """mj_decode_static: the files (bytes or PinnedFiles) decoded into the caller's device
+        buffers with no device allocation.  Returns a Batch view owned by the context."""
+        ptrs, lens, n, keep = _file_args(files)
+        view = C.c_void_p()
+        _check(self.lib, self.lib.mj_decode_static(self.h, ptrs, lens, n, flags, C.c_void_p(dev_coefs), coefs_bytes,
+                                                   C.c_void_p(dev_rgb), rgb_bytes, C.byref(view)), "mj_decode_static")
+        return Batch._view(self, view, n, flags, keep)
 
     def close(self):
         if self.h:
@@ -200,7 +210,7 @@ class Batch:
 
     @classmethod
     def _view(cls, ctx, handle, n, flags, keep):
-        """A batch owned by the library (a pipeline slot): never destroyed from here."""
+        """A batch owned by the library (a pipeline slot, the static batch): never destroyed from here."""
         self = cls.__new__(cls)
         self.ctx, self.lib, self.h, self.n, self.flags, self.owned, self._keep = ctx, ctx.lib, handle, n, flags, False, keep
         return self

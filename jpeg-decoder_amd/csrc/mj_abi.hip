@@ -14,7 +14,8 @@
  *          never cleared: every kernel writes what a later one reads;
  *   out    coefficients, RGB and optional planes.
  * mj_batch_create and the pipeline put all four in one allocation per batch (or
- * pipeline slot).
+ * pipeline slot); mj_decode_static puts the first three in a file-scope device array
+ * and takes `out` from the caller.
  */
 #include <hip/hip_runtime.h>
 
@@ -27,6 +28,11 @@
 #include "../host/mj_host.h"
 #include "mi355jpeg.h"
 #include "mj_internal.h"
+
+/* Work memory of mj_decode_static: one copy per GPU, held from the moment the library's
+ * code is loaded on that GPU until the process ends.  In host code this name is only a
+ * handle for hipGetSymbolAddress (see mj_create); kernels get the address as an argument. */
+static __device__ __align__(256) unsigned char scratch[MJ_STATIC_SCRATCH_BYTES];
 
 namespace {
 
@@ -58,6 +64,8 @@ struct EventSet {
     hipEvent_t ev[MJ_T_COUNT + 1];
 };
 constexpr int kSlotOf[MJ_T_COUNT] = {MJ_T_MEMSET, MJ_T_SCAN, MJ_T_ENTROPY, MJ_T_ENTROPY_FIX, MJ_T_IDCT_COLOUR};
+
+constexpr size_t kStaticMetaBytes = 4u << 20;   /* page-locked mirror of the meta region of mj_decode_static */
 
 /* offsets of every device buffer inside its region (all multiples of 256) */
 struct Offsets {
@@ -99,6 +107,9 @@ struct mj_ctx {
     size_t arena_cap = 0;
     uint8_t *meta_host = nullptr;
     size_t meta_cap = 0;
+    /* mj_decode_static: this device's copy of `scratch`, and the one batch object that lives in it */
+    uint8_t *scratch_dev = nullptr;
+    mj_batch *sbatch = nullptr;
 };
 
 struct mj_batch {
@@ -110,12 +121,13 @@ struct mj_batch {
     std::vector<uint32_t> tile_img, wg_img, idct_img, idct_first;
     Offsets o{};
     uint64_t raw_bytes = 0;
-    uint8_t *arena = nullptr;      /* meta | state | work | out, one allocation */
+    uint8_t *arena = nullptr;      /* meta | state | work | out, one allocation (null for the static batch) */
     size_t arena_cap = 0;
     uint8_t *meta_host = nullptr;  /* page-locked mirror of the meta region */
     size_t meta_cap = 0;
     uint8_t *stage = nullptr;      /* pipeline slots: own staging for pageable input (a one-shot batch uses the context's) */
     size_t stage_cap = 0;
+    bool borrowed = false;         /* static batch: no device memory of its own to free */
     MjDeviceBatch d{};
     uint64_t coef_bytes = 0, rgb_bytes = 0, plane_bytes = 0;
     hipStream_t stream = nullptr;  /* the stream the last decode was enqueued on */
@@ -530,7 +542,7 @@ void batch_free(mj_batch *b, bool park) {
         for (hipEvent_t ev : es.ev) (void) hipEventDestroy(ev);
     }
     mj_ctx *c = b->ctx;
-    if (b->arena) {
+    if (b->arena && !b->borrowed) {
         if (park && c->arena && c->arena_cap < b->arena_cap) {
             (void) hipFree(c->arena);
             c->arena = nullptr;
@@ -654,6 +666,29 @@ int mj_create(int device, mj_ctx **out) {
         return set_err("mj_create: hipStreamCreate failed: %s", hipGetErrorString(e));
     }
     c->stream = c->own;
+    /* this device's copy of the static work memory: with the device current, ask the
+     * runtime where it is; from here on only that address is used, never the array's name */
+    void *sp = nullptr;
+    e = hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch));
+    if (e == hipSuccess && sp) {
+        c->scratch_dev = static_cast<uint8_t *>(sp);
+        c->sbatch = batch_new(c);
+        if (c->sbatch) {
+            c->sbatch->borrowed = true;
+            if (hipHostMalloc(reinterpret_cast<void **>(&c->sbatch->meta_host), kStaticMetaBytes, hipHostMallocDefault) == hipSuccess) {
+                c->sbatch->meta_cap = kStaticMetaBytes;
+            } else {
+                c->sbatch->meta_host = nullptr;
+                batch_free(c->sbatch, false);
+                c->sbatch = nullptr;
+            }
+        }
+    }
+    if (!c->sbatch) {
+        /* the context still serves every other entry point; mj_decode_static reports this */
+        c->scratch_dev = nullptr;
+        (void) hipGetLastError();
+    }
     *out = c;
     return 0;
 }
@@ -664,6 +699,7 @@ void mj_destroy(mj_ctx *ctx) {
     (void) hipStreamSynchronize(ctx->stream);
     (void) hipStreamSynchronize(ctx->own);
     (void) hipStreamSynchronize(ctx->copy);
+    if (ctx->sbatch) batch_free(ctx->sbatch, false);
     (void) hipStreamDestroy(ctx->own);
     (void) hipStreamDestroy(ctx->copy);
     if (ctx->stage) (void) hipHostFree(ctx->stage);
@@ -692,7 +728,7 @@ void mj_host_free(void *p) {
 }
 
 void mj_batch_destroy(mj_batch *b) {
-    if (!b) return;
+    if (!b || b->borrowed) return;   /* the view mj_decode_static hands out belongs to the context */
     (void) hipSetDevice(b->ctx->device);
     /* the stream every decode of this batch went to, whatever the context's current one is */
     (void) batch_wait(b);
@@ -788,6 +824,49 @@ int mj_pipe_submit(mj_pipe *p, const uint8_t *const *bufs, const size_t *lens, i
     if (enqueue_decode(b, ctx->stream) != 0) return -1;
     p->next++;
     *out = b;
+    return 0;
+}
+
+/* ---- the entry point that allocates nothing --------------------------------------- */
+
+int mj_decode_static(mj_ctx *ctx, const uint8_t *const *bufs, const size_t *lens, int n, uint32_t flags, void *dev_coefs,
+                     size_t coefs_bytes, void *dev_rgb, size_t rgb_bytes, mj_batch **view) {
+    if (!ctx || !bufs || !lens || n <= 0 || !dev_coefs || !dev_rgb) return set_err("mj_decode_static: bad arguments");
+    if (flags & ~(uint32_t) MJ_OUT_RGBA) return set_err("mj_decode_static: only MJ_OUT_RGBA is accepted here (flags 0x%x)", flags);
+    if (!ctx->sbatch || !ctx->scratch_dev) return set_err("mj_decode_static: the static work memory could not be located on this device");
+    if (((uintptr_t) dev_coefs & 15u) || ((uintptr_t) dev_rgb & 15u)) return set_err("mj_decode_static: output buffers must be 16-byte aligned");
+    HIP_TRY(hipSetDevice(ctx->device));
+    mj_batch *b = ctx->sbatch;
+    /* every call on this GPU uses the same work memory: the previous call must be over */
+    if (batch_wait(b)) return -1;
+    std::vector<MjPrepared> prep;
+    if (prepare(bufs, lens, n, prep, "mj_decode_static")) return -1;
+    if (layout(b, prep, flags)) return -1;
+    const Offsets &o = b->o;
+    const size_t need = o.meta_bytes + o.state_bytes + o.work_bytes;
+    if (need > (size_t) MJ_STATIC_SCRATCH_BYTES || o.meta_bytes > b->meta_cap) {
+        b->decoded = false;
+        return set_err("mj_decode_static: this batch needs %zu bytes of work memory (%zu of them descriptors); the static limits are %zu and %zu",
+                       need, o.meta_bytes, (size_t) MJ_STATIC_SCRATCH_BYTES, b->meta_cap);
+    }
+    if (b->coef_bytes > coefs_bytes || b->rgb_bytes > rgb_bytes) {
+        b->decoded = false;
+        return set_err("mj_decode_static: outputs need %llu bytes of coefficients and %llu of RGB; %zu and %zu were passed",
+                       (unsigned long long) b->coef_bytes, (unsigned long long) b->rgb_bytes, coefs_bytes, rgb_bytes);
+    }
+    uint8_t *meta = ctx->scratch_dev, *state = meta + o.meta_bytes, *work = state + o.state_bytes;
+    bind(b, meta, state, work, static_cast<uint8_t *>(dev_coefs), static_cast<uint8_t *>(dev_rgb), nullptr);
+    hipStream_t s = ctx->stream;
+    /* uploads and kernels in order on one stream; the state region is cleared there first */
+    b->uploaded_async = false;
+    b->decoded = false;
+    if (upload(b, prep, meta, state, nullptr, s)) return -1;
+    HIP_TRY(hipEventRecord(b->ev_up, s));
+    if (enqueue_decode(b, s)) return -1;
+    if (view) *view = b;
+    /* the caller's buffers and the descriptor mirror are free once the upload is through;
+     * the kernels run on */
+    HIP_TRY(hipEventSynchronize(b->ev_up));
     return 0;
 }
 
