@@ -114,6 +114,11 @@ typedef struct mj_pipe mj_pipe;
 int mj_pipe_create(mj_ctx *ctx, int depth, uint32_t flags, mj_pipe **out);
 int mj_pipe_submit(mj_pipe *p, const uint8_t *const *bufs, const size_t *lens, int n, mj_batch **out);
 void mj_pipe_destroy(mj_pipe *p);
+/* Host time spent inside mj_pipe_submit since the pipeline was created (or since the last
+ * call with reset != 0), in milliseconds: waiting for the slot to come free (the GPU is
+ * the slower side) and working (header parse, table flattening, layout, enqueueing);
+ * *submits counts all submits so far. */
+int mj_pipe_host_ms(mj_pipe *p, double *wait_ms, double *work_ms, int64_t *submits, int reset);
 
 /* No counterpart in the reference.  For callers that cannot allocate device memory
  * (code under HIP graph capture, tight serving loops, harnesses that forbid it):

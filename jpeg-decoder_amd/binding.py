@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "mj_batch_decode", "mj_batch_sync", "mj_batch_size", "mj_batch_image_info", "mj_batch_status",
     "mj_batch_device_rgb", "mj_batch_device_coefs", "mj_batch_copy_rgb", "mj_batch_copy_coefs",
     "mj_batch_copy_plane", "mj_batch_kernel_ms", "mj_batch_reset_timing", "mj_batch_entropy_stats",
-    "mj_host_alloc", "mj_host_free", "mj_pipe_create", "mj_pipe_submit", "mj_pipe_destroy", "mj_decode_static",
+    "mj_host_alloc", "mj_host_free", "mj_pipe_create", "mj_pipe_submit", "mj_pipe_destroy", "mj_pipe_host_ms", "mj_decode_static",
 ]
 COMPAT_SYMBOLS = [
     "get_byte", "next_byte", "next_bit", "next_bit_size", "check_marker", "next_byte_restart_marker", "progress",
@@ -93,6 +93,7 @@ def load_library():
     lib.mj_pipe_create.argtypes = [vp, i32, u32, C.POINTER(vp)]
     lib.mj_pipe_submit.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), i32, C.POINTER(vp)]
     lib.mj_pipe_destroy.argtypes = [vp]
+    lib.mj_pipe_host_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]
     lib.mj_pipe_destroy.restype = None
     lib.mj_decode_static.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), i32, u32, vp, C.c_size_t, vp, C.c_size_t,
                                      C.POINTER(vp)]
@@ -152,12 +153,16 @@ class PinnedFiles:
     starting on a 64-byte boundary: what a caller that wants the copy to HBM to run straight
     from its buffers hands to Batch / Pipe.submit."""
 
-    def __init__(self, files):
+    def __init__(self, files, descending=False):
+        """descending: lay the files out in memory in the opposite order of the list (a list
+        whose files are not in ascending address order goes to HBM one copy per image instead
+        of as one stretch)."""
         self.lib = load_library()
-        offs, at = [], 0
-        for f in files:
-            offs.append(at)
-            at += (len(f) + 63) // 64 * 64
+        offs, at = [0] * len(files), 0
+        order = range(len(files) - 1, -1, -1) if descending else range(len(files))
+        for i in order:
+            offs[i] = at
+            at += (len(files[i]) + 63) // 64 * 64
         self.bytes = max(at, 64)
         self.base = self.lib.mj_host_alloc(self.bytes)
         if not self.base:
@@ -302,6 +307,12 @@ class Pipe:
         out = C.c_void_p()
         _check(self.lib, self.lib.mj_pipe_submit(self.h, ptrs, lens, n, C.byref(out)), "mj_pipe_submit")
         return Batch._view(self.ctx, out, n, self.flags, keep)
+
+    def host_ms(self, reset=False):
+        """(ms waiting for a free slot, ms of host work, submits so far) inside submit()."""
+        w, k, n = C.c_double(), C.c_double(), C.c_int64()
+        _check(self.lib, self.lib.mj_pipe_host_ms(self.h, C.byref(w), C.byref(k), C.byref(n), 1 if reset else 0), "mj_pipe_host_ms")
+        return w.value, k.value, n.value
 
     def close(self):
         if self.h:

@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <vector>
 
 #include "../host/mj_host.h"
@@ -65,6 +66,10 @@ struct EventSet {
 };
 constexpr int kSlotOf[MJ_T_COUNT] = {MJ_T_MEMSET, MJ_T_SCAN, MJ_T_ENTROPY, MJ_T_ENTROPY_FIX, MJ_T_IDCT_COLOUR};
 
+/* Upload streams per context.  (Spreading the per-image copies of a batch over four
+ * streams was measured and is slower than one: 4.5 against 4.1 ms per 64 images of 2 MB.) */
+constexpr int kCopyStreams = 1;
+
 constexpr size_t kStaticMetaBytes = 4u << 20;   /* page-locked mirror of the meta region of mj_decode_static */
 
 /* offsets of every device buffer inside its region (all multiples of 256) */
@@ -93,8 +98,8 @@ struct Carve {
 
 struct mj_ctx {
     int device;
-    hipStream_t own;      /* the context's compute stream */
-    hipStream_t copy;     /* uploads */
+    hipStream_t own = nullptr;   /* the context's compute stream */
+    hipStream_t copy[kCopyStreams];   /* uploads; [0] also carries the memset and the descriptors */
     hipStream_t stream;   /* where decodes are enqueued: own, or the caller's (mj_set_stream) */
     /* page-locked staging for entropy-coded bytes handed over in pageable memory and for
      * result read-back; kept and grown from one batch to the next */
@@ -121,6 +126,8 @@ struct mj_batch {
     std::vector<uint32_t> tile_img, wg_img, idct_img, idct_first;
     Offsets o{};
     uint64_t raw_bytes = 0;
+    const uint8_t *span_src = nullptr;   /* non-null: the images' bytes lie close together in page-locked memory and leave as one copy from here */
+    uint64_t span_bytes = 0;
     uint8_t *arena = nullptr;      /* meta | state | work | out, one allocation (null for the static batch) */
     size_t arena_cap = 0;
     uint8_t *meta_host = nullptr;  /* page-locked mirror of the meta region */
@@ -131,8 +138,9 @@ struct mj_batch {
     MjDeviceBatch d{};
     uint64_t coef_bytes = 0, rgb_bytes = 0, plane_bytes = 0;
     hipStream_t stream = nullptr;  /* the stream the last decode was enqueued on */
-    hipEvent_t ev_up = nullptr, ev_done = nullptr;
-    bool uploaded_async = false;   /* ev_up is pending on the copy stream */
+    hipEvent_t ev_up[kCopyStreams] = {nullptr}, ev_done = nullptr;
+    int n_up = 0;                  /* copy streams the last upload used: ev_up[0 .. n_up) were recorded */
+    bool uploaded_async = false;   /* those events are pending */
     bool decoded = false;          /* ev_done has been recorded */
     std::vector<EventSet> pending, pool;
     float ms[MJ_T_COUNT] = {0};
@@ -144,13 +152,24 @@ struct mj_pipe {
     uint32_t flags = 0;
     std::vector<mj_batch *> slots;
     uint64_t next = 0;
+    double wait_ms = 0, host_ms = 0;   /* per submit: waiting for the slot; parse + layout + enqueue */
 };
 
-/* One image ready for placement: flattened descriptor + tables + its entropy bytes. */
+/* One image ready for placement: flattened descriptor, which of the call's Huffman sets
+ * it uses, and its entropy bytes. */
 struct MjPrepared {
     MjImageDev im;
-    MjHuffSet set;
+    uint32_t set;
     const uint8_t *ent;
+};
+
+/* The images of one call and the distinct Huffman sets among them (mostly one: an
+ * encoder's default tables).  A set is built for the first image with a given key only. */
+struct MjPrep {
+    std::vector<MjPrepared> img;
+    std::vector<MjHuffSet> sets;
+    std::vector<uint8_t> keys;       /* MJ_HUFF_KEY_BYTES per set */
+    std::vector<size_t> key_len;
 };
 
 namespace {
@@ -188,9 +207,13 @@ int collect_timing(mj_batch *b) {
 mj_batch *batch_new(mj_ctx *ctx) {
     mj_batch *b = new mj_batch();
     b->ctx = ctx;
-    if (hipEventCreateWithFlags(&b->ev_up, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&b->ev_done, hipEventDisableTiming) != hipSuccess) {
-        if (b->ev_up) (void) hipEventDestroy(b->ev_up);
+    bool ok = hipEventCreateWithFlags(&b->ev_done, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < kCopyStreams && ok; i++) ok = hipEventCreateWithFlags(&b->ev_up[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        for (hipEvent_t e : b->ev_up) {
+            if (e) (void) hipEventDestroy(e);
+        }
+        if (b->ev_done) (void) hipEventDestroy(b->ev_done);
         delete b;
         set_err("cannot create HIP events");
         return nullptr;
@@ -201,16 +224,46 @@ mj_batch *batch_new(mj_ctx *ctx) {
 /* wait for everything enqueued for the batch: its upload and its last decode */
 int batch_wait(mj_batch *b) {
     if (b->uploaded_async) {
-        HIP_TRY(hipEventSynchronize(b->ev_up));
+        for (int i = 0; i < b->n_up; i++) HIP_TRY(hipEventSynchronize(b->ev_up[i]));
         b->uploaded_async = false;
     }
     if (b->decoded) HIP_TRY(hipEventSynchronize(b->ev_done));
     return 0;
 }
 
+/* index of the set with this key among those of the call, or -1 */
+int find_set(const MjPrep &pp, const uint8_t *key, size_t len) {
+    for (size_t i = 0; i < pp.key_len.size(); i++) {
+        if (pp.key_len[i] == len && memcmp(&pp.keys[i * MJ_HUFF_KEY_BYTES], key, len) == 0) return (int) i;
+    }
+    return -1;
+}
+
+/* one image's parsed headers -> descriptor, building its Huffman set unless the call has it */
+int prepare_one(MjPrep &pp, size_t i, const MjParsed &P, size_t len_after_headers_base, const char **why) {
+    uint8_t key[MJ_HUFF_KEY_BYTES];
+    const size_t klen = mj_huff_key(&P, key);
+    int si = find_set(pp, key, klen);
+    if (si >= 0) {
+        if (mj_flatten_image(&P, len_after_headers_base, &pp.img[i].im, nullptr, why) != 0) return -1;
+    } else {
+        pp.sets.emplace_back();
+        if (mj_flatten_image(&P, len_after_headers_base, &pp.img[i].im, &pp.sets.back(), why) != 0) {
+            pp.sets.pop_back();
+            return -1;
+        }
+        si = (int) pp.sets.size() - 1;
+        pp.keys.resize(pp.sets.size() * MJ_HUFF_KEY_BYTES);
+        memcpy(&pp.keys[(size_t) si * MJ_HUFF_KEY_BYTES], key, klen);
+        pp.key_len.push_back(klen);
+    }
+    pp.img[i].set = (uint32_t) si;
+    return 0;
+}
+
 /* host: headers -> descriptors (decode.c:160-415 marker walk + table flattening) */
-int prepare(const uint8_t *const *bufs, const size_t *lens, int n, std::vector<MjPrepared> &prep, const char *who) {
-    prep.resize(n);
+int prepare(const uint8_t *const *bufs, const size_t *lens, int n, MjPrep &pp, const char *who) {
+    pp.img.resize(n);
     for (int i = 0; i < n; i++) {
         MjParsed P;
         const char *why = "?";
@@ -218,23 +271,57 @@ int prepare(const uint8_t *const *bufs, const size_t *lens, int n, std::vector<M
         if (mj_parse_headers(bufs[i], lens[i], &P, &why) != 0) {
             return set_err("%s: image %d: %s", who, i, why);   /* the parser freed what it had */
         }
-        if (mj_flatten_image(&P, lens[i], &prep[i].im, &prep[i].set, &why) != 0) {
+        if (prepare_one(pp, (size_t) i, P, lens[i], &why) != 0) {
             mj_parsed_free(&P);
             return set_err("%s: image %d: %s", who, i, why);
         }
-        prep[i].ent = bufs[i] + P.ent_pos;
+        pp.img[i].ent = bufs[i] + P.ent_pos;
         mj_parsed_free(&P);
     }
     return 0;
 }
 
 /* host: where every image and every table goes; no HIP call */
-int layout(mj_batch *b, const std::vector<MjPrepared> &prep, uint32_t flags) {
+/* Do the entropy-coded segments lie in ascending order inside one stretch of page-locked
+ * memory with little else between them (the files of a batch loaded back to back)?  Then
+ * the stretch is copied whole -- one DMA instead of one per image, each of which costs
+ * about as much again in set-up as it takes to move 2 MB -- and every image is read where
+ * it lands: the scan kernels accept any byte alignment. */
+bool find_span(const std::vector<MjPrepared> &prep, const uint8_t **src, uint64_t *bytes) {
+    if (prep.size() < 2) return false;
+    uint64_t sum = 0;
+    for (size_t i = 0; i < prep.size(); i++) {
+        sum += prep[i].im.raw_len;
+        if (i && prep[i].ent < prep[i - 1].ent + prep[i - 1].im.raw_len) return false;
+    }
+    const uint8_t *first = prep.front().ent, *last = prep.back().ent + prep.back().im.raw_len;
+    const uint64_t span = (uint64_t) (last - first);
+    if (span > sum + sum / 16 + 4096 * prep.size() || span >= (1ull << 40)) return false;
+    hipPointerAttribute_t a, z;
+    memset(&a, 0, sizeof a);
+    memset(&z, 0, sizeof z);
+    if (hipPointerGetAttributes(&a, first) != hipSuccess || hipPointerGetAttributes(&z, last - 1) != hipSuccess) {
+        (void) hipGetLastError();
+        return false;
+    }
+    if (a.type != hipMemoryTypeHost || z.type != hipMemoryTypeHost || a.hostPointer == nullptr || z.hostPointer == nullptr) return false;
+    /* one allocation: the distance between the two host addresses equals that between their device views */
+    if ((const uint8_t *) z.devicePointer - (const uint8_t *) a.devicePointer != (last - 1) - first) return false;
+    *src = first;
+    *bytes = span;
+    return true;
+}
+
+int layout(mj_batch *b, const MjPrep &pp, uint32_t flags, bool may_span) {
+    const std::vector<MjPrepared> &prep = pp.img;
     const int n = (int) prep.size();
+    b->span_src = nullptr;
+    b->span_bytes = 0;
+    if (may_span && !find_span(prep, &b->span_src, &b->span_bytes)) b->span_src = nullptr;
     b->flags = flags;
     b->img.resize(n);
     b->info.resize(n);
-    b->sets.clear();
+    b->sets = pp.sets;
     b->tile_img.clear();
     b->wg_img.clear();
     b->idct_img.clear();
@@ -245,20 +332,18 @@ int layout(mj_batch *b, const std::vector<MjPrepared> &prep, uint32_t flags) {
     for (int i = 0; i < n; i++) {
         MjImageDev &im = b->img[i];
         im = prep[i].im;
-        const MjHuffSet &set = prep[i].set;
         if (im.raw_len >= (1ull << 28)) {
             return set_err("image %d: entropy segment of %llu bytes is too large", i, (unsigned long long) im.raw_len);
         }
-        /* images with identical tables share one set */
-        uint32_t si = 0;
-        for (; si < b->sets.size(); si++) {
-            if (memcmp(&b->sets[si], &set, sizeof set) == 0) break;
-        }
-        if (si == b->sets.size()) b->sets.push_back(set);
-        im.huff_set = si;
+        im.huff_set = prep[i].set;      /* images with identical tables share one set */
 
-        im.raw_off = raw_total;
-        raw_total = align_up(raw_total + im.raw_len + 32, 16);
+        if (b->span_src) {
+            im.raw_off = (uint64_t) (prep[i].ent - b->span_src);   /* where the image lands: any alignment */
+            raw_total = align_up(b->span_bytes + 32, 16);
+        } else {
+            im.raw_off = raw_total;
+            raw_total = align_up(raw_total + im.raw_len + 32, 16);
+        }
         im.cmp_off = cmp_total;
         cmp_total = align_up(cmp_total + im.raw_len + MJ_STREAM_PAD, 16);
         im.coef_off = coef_blocks;
@@ -432,10 +517,13 @@ int arena_reserve(mj_batch *b, size_t need) {
         ctx->arena = nullptr;
         ctx->arena_cap = 0;
     }
+    /* a little more than asked: the next batch of the same shape rarely compresses to the
+     * very same size, and growing means freeing and allocating gigabytes */
+    const size_t want = need + need / 16;
     void *p = nullptr;
-    if (hipMalloc(&p, need) != hipSuccess) return set_err("cannot allocate %zu bytes of device memory", need);
+    if (hipMalloc(&p, want) != hipSuccess) return set_err("cannot allocate %zu bytes of device memory", want);
     b->arena = static_cast<uint8_t *>(p);
-    b->arena_cap = need;
+    b->arena_cap = want;
     return 0;
 }
 
@@ -456,13 +544,17 @@ bool all_page_locked(const std::vector<MjPrepared> &prep) {
     return true;
 }
 
-/* Enqueue on `s`: clear the state region, send the meta region and the entropy-coded
- * bytes.  meta/state: device addresses of the regions.  With stage == nullptr every
- * image's bytes go straight from the caller's memory, one copy per image; otherwise they
- * are gathered in `stage` (page-locked, at least raw_bytes) first and leave as one copy.
- * Allocates nothing. */
-int upload(mj_batch *b, const std::vector<MjPrepared> &prep, uint8_t *meta, uint8_t *state, uint8_t *stage, hipStream_t s) {
+/* Enqueue on the streams ss[0 .. ns): clear the state region, send the meta region and
+ * the entropy-coded bytes.  meta/state: device addresses of the regions.  With
+ * stage == nullptr every image's bytes go straight from the caller's memory, one copy per
+ * image, round-robin over the streams; otherwise they are gathered in `stage`
+ * (page-locked, at least raw_bytes) first and leave as one copy.  Returns the number of
+ * streams used through *used.  Allocates nothing. */
+int upload(mj_batch *b, const std::vector<MjPrepared> &prep, uint8_t *meta, uint8_t *state, uint8_t *stage, const hipStream_t *ss,
+           int ns, int *used) {
     const Offsets &o = b->o;
+    hipStream_t s = ss[0];
+    *used = 1;
     HIP_TRY(hipMemsetAsync(state, 0, o.state_bytes, s));
     uint8_t *mh = b->meta_host;
     const size_t n = b->img.size();
@@ -474,12 +566,16 @@ int upload(mj_batch *b, const std::vector<MjPrepared> &prep, uint8_t *meta, uint
     memcpy(mh + o.idct_first, b->idct_first.data(), n * 4);
     HIP_TRY(hipMemcpyAsync(meta, mh, o.meta_bytes, hipMemcpyHostToDevice, s));
     uint8_t *raw = const_cast<uint8_t *>(b->d.raw);
-    if (stage) {
+    if (b->span_src) {
+        HIP_TRY(hipMemcpyAsync(raw, b->span_src, b->span_bytes, hipMemcpyHostToDevice, s));
+    } else if (stage) {
         for (size_t i = 0; i < n; i++) memcpy(stage + b->img[i].raw_off, prep[i].ent, b->img[i].raw_len);
         HIP_TRY(hipMemcpyAsync(raw, stage, b->raw_bytes, hipMemcpyHostToDevice, s));
     } else {
         for (size_t i = 0; i < n; i++) {
-            if (b->img[i].raw_len) HIP_TRY(hipMemcpyAsync(raw + b->img[i].raw_off, prep[i].ent, b->img[i].raw_len, hipMemcpyHostToDevice, s));
+            const int k = (int) (i % (size_t) ns);
+            if (k + 1 > *used) *used = k + 1;
+            if (b->img[i].raw_len) HIP_TRY(hipMemcpyAsync(raw + b->img[i].raw_off, prep[i].ent, b->img[i].raw_len, hipMemcpyHostToDevice, ss[k]));
         }
     }
     return 0;
@@ -505,7 +601,9 @@ int enqueue_decode(mj_batch *b, hipStream_t s) {
     }
     auto mark = [&](int i) -> hipError_t { return timing ? hipEventRecord(es.ev[i], s) : hipSuccess; };
     b->stream = s;
-    if (b->uploaded_async) HIP_TRY(hipStreamWaitEvent(s, b->ev_up, 0));
+    if (b->uploaded_async) {
+        for (int i = 0; i < b->n_up; i++) HIP_TRY(hipStreamWaitEvent(s, b->ev_up[i], 0));
+    }
 
     HIP_TRY(mark(0));
     HIP_TRY(hipMemsetAsync(b->d.stats, 0, MJ_ST_COUNT * sizeof(unsigned long long), s));
@@ -567,7 +665,9 @@ void batch_free(mj_batch *b, bool park) {
         }
     }
     if (b->stage) (void) hipHostFree(b->stage);
-    if (b->ev_up) (void) hipEventDestroy(b->ev_up);
+    for (hipEvent_t e : b->ev_up) {
+        if (e) (void) hipEventDestroy(e);
+    }
     if (b->ev_done) (void) hipEventDestroy(b->ev_done);
     delete b;
 }
@@ -575,9 +675,10 @@ void batch_free(mj_batch *b, bool park) {
 /* lay the images out in the batch's own allocation and send them on the copy stream;
  * with `wait` the call returns when the copies are through (the caller's buffers are
  * then free) */
-int fill_own(mj_batch *b, const std::vector<MjPrepared> &prep, uint32_t flags, bool own_stage, bool wait) {
+int fill_own(mj_batch *b, const MjPrep &pp, uint32_t flags, bool own_stage, bool wait) {
     mj_ctx *ctx = b->ctx;
-    if (layout(b, prep, flags)) return -1;
+    const std::vector<MjPrepared> &prep = pp.img;
+    if (layout(b, pp, flags, true)) return -1;
     const Offsets &o = b->o;
     const size_t need = o.meta_bytes + o.state_bytes + o.work_bytes + o.out_bytes;
     if (arena_reserve(b, need)) return -1;
@@ -591,7 +692,7 @@ int fill_own(mj_batch *b, const std::vector<MjPrepared> &prep, uint32_t flags, b
     uint8_t *meta = b->arena, *state = meta + o.meta_bytes, *work = state + o.state_bytes, *out = work + o.work_bytes;
     bind(b, meta, state, work, out + o.coefs, out + o.rgb, b->plane_bytes ? out + o.planes : nullptr);
     uint8_t *stage = nullptr;
-    if (!all_page_locked(prep)) {
+    if (!b->span_src && !all_page_locked(prep)) {
         if (own_stage) {
             if (host_reserve(&b->stage, &b->stage_cap, b->raw_bytes, "staging the entropy-coded bytes")) return -1;
             stage = b->stage;
@@ -600,14 +701,11 @@ int fill_own(mj_batch *b, const std::vector<MjPrepared> &prep, uint32_t flags, b
             stage = ctx->stage;
         }
     }
-    if (upload(b, prep, meta, state, stage, ctx->copy)) return -1;
-    HIP_TRY(hipEventRecord(b->ev_up, ctx->copy));
+    if (upload(b, prep, meta, state, stage, ctx->copy, kCopyStreams, &b->n_up)) return -1;
+    for (int i = 0; i < b->n_up; i++) HIP_TRY(hipEventRecord(b->ev_up[i], ctx->copy[i]));
     b->uploaded_async = true;
     b->decoded = false;
-    if (wait) {
-        HIP_TRY(hipEventSynchronize(b->ev_up));
-        b->uploaded_async = false;
-    }
+    if (wait && batch_wait(b)) return -1;
     return 0;
 }
 
@@ -621,7 +719,7 @@ int check_flags(uint32_t flags, const char *who) {
     return 0;
 }
 
-int batch_build(mj_ctx *ctx, std::vector<MjPrepared> &prep, uint32_t flags, mj_batch **out, const char *who) {
+int batch_build(mj_ctx *ctx, const MjPrep &prep, uint32_t flags, mj_batch **out, const char *who) {
     if (check_flags(flags, who)) return -1;
     HIP_TRY(hipSetDevice(ctx->device));
     mj_batch *b = batch_new(ctx);
@@ -656,12 +754,14 @@ int mj_create(int device, mj_ctx **out) {
     HIP_TRY(hipSetDevice(device));
     mj_ctx *c = new mj_ctx();
     c->device = device;
+    for (hipStream_t &cs : c->copy) cs = nullptr;
     e = hipStreamCreateWithFlags(&c->own, hipStreamNonBlocking);
-    if (e == hipSuccess) {
-        e = hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking);
-        if (e != hipSuccess) (void) hipStreamDestroy(c->own);
-    }
+    for (int i = 0; i < kCopyStreams && e == hipSuccess; i++) e = hipStreamCreateWithFlags(&c->copy[i], hipStreamNonBlocking);
     if (e != hipSuccess) {
+        if (c->own) (void) hipStreamDestroy(c->own);
+        for (hipStream_t cs : c->copy) {
+            if (cs) (void) hipStreamDestroy(cs);
+        }
         delete c;
         return set_err("mj_create: hipStreamCreate failed: %s", hipGetErrorString(e));
     }
@@ -698,10 +798,10 @@ void mj_destroy(mj_ctx *ctx) {
     (void) hipSetDevice(ctx->device);
     (void) hipStreamSynchronize(ctx->stream);
     (void) hipStreamSynchronize(ctx->own);
-    (void) hipStreamSynchronize(ctx->copy);
+    for (hipStream_t cs : ctx->copy) (void) hipStreamSynchronize(cs);
     if (ctx->sbatch) batch_free(ctx->sbatch, false);
     (void) hipStreamDestroy(ctx->own);
-    (void) hipStreamDestroy(ctx->copy);
+    for (hipStream_t cs : ctx->copy) (void) hipStreamDestroy(cs);
     if (ctx->stage) (void) hipHostFree(ctx->stage);
     if (ctx->meta_host) (void) hipHostFree(ctx->meta_host);
     if (ctx->arena) (void) hipFree(ctx->arena);
@@ -739,7 +839,7 @@ void mj_batch_destroy(mj_batch *b) {
 int mj_batch_create(mj_ctx *ctx, const uint8_t *const *bufs, const size_t *lens, int n, uint32_t flags,
                     mj_batch **out) {
     if (!ctx || !bufs || !lens || !out || n <= 0) return set_err("mj_batch_create: bad arguments");
-    std::vector<MjPrepared> prep;
+    MjPrep prep;
     if (prepare(bufs, lens, n, prep, "mj_batch_create")) return -1;
     return batch_build(ctx, prep, flags, out, "mj_batch_create");
 }
@@ -756,12 +856,13 @@ int mj_batch_create_scan(mj_ctx *ctx, const uint8_t *entropy, size_t entropy_len
     P.qts = *qts;
     P.ri = ri;
     P.ent_pos = 0;
-    std::vector<MjPrepared> prep(1);
+    MjPrep prep;
+    prep.img.resize(1);
     const char *why = "?";
-    if (mj_flatten_image(&P, entropy_len, &prep[0].im, &prep[0].set, &why) != 0) {
+    if (prepare_one(prep, 0, P, entropy_len, &why) != 0) {
         return set_err("mj_batch_create_scan: %s", why);
     }
-    prep[0].ent = entropy;
+    prep.img[0].ent = entropy;
     return batch_build(ctx, prep, flags, out, "mj_batch_create_scan");
 }
 
@@ -815,15 +916,32 @@ int mj_pipe_submit(mj_pipe *p, const uint8_t *const *bufs, const size_t *lens, i
     mj_ctx *ctx = p->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
     mj_batch *b = p->slots[p->next % p->slots.size()];
+    using clk = std::chrono::steady_clock;
+    const clk::time_point t0 = clk::now();
     /* the slot's previous occupant: its decode must be over before its memory (device and
      * page-locked mirrors) is written again */
     if (batch_wait(b)) return -1;
-    std::vector<MjPrepared> prep;
+    const clk::time_point t1 = clk::now();
+    MjPrep prep;
     if (prepare(bufs, lens, n, prep, "mj_pipe_submit")) return -1;
     if (fill_own(b, prep, p->flags, true, false) != 0) return -1;
     if (enqueue_decode(b, ctx->stream) != 0) return -1;
+    const clk::time_point t2 = clk::now();
+    p->wait_ms += std::chrono::duration<double, std::milli>(t1 - t0).count();
+    p->host_ms += std::chrono::duration<double, std::milli>(t2 - t1).count();
     p->next++;
     *out = b;
+    return 0;
+}
+
+int mj_pipe_host_ms(mj_pipe *p, double *wait_ms, double *work_ms, int64_t *submits, int reset) {
+    if (!p) return set_err("mj_pipe_host_ms: null pipeline");
+    if (wait_ms) *wait_ms = p->wait_ms;
+    if (work_ms) *work_ms = p->host_ms;
+    if (submits) *submits = (int64_t) p->next;
+    if (reset) {
+        p->wait_ms = p->host_ms = 0;
+    }
     return 0;
 }
 
@@ -839,9 +957,9 @@ int mj_decode_static(mj_ctx *ctx, const uint8_t *const *bufs, const size_t *lens
     mj_batch *b = ctx->sbatch;
     /* every call on this GPU uses the same work memory: the previous call must be over */
     if (batch_wait(b)) return -1;
-    std::vector<MjPrepared> prep;
+    MjPrep prep;
     if (prepare(bufs, lens, n, prep, "mj_decode_static")) return -1;
-    if (layout(b, prep, flags)) return -1;
+    if (layout(b, prep, flags, true)) return -1;
     const Offsets &o = b->o;
     const size_t need = o.meta_bytes + o.state_bytes + o.work_bytes;
     if (need > (size_t) MJ_STATIC_SCRATCH_BYTES || o.meta_bytes > b->meta_cap) {
@@ -860,13 +978,13 @@ int mj_decode_static(mj_ctx *ctx, const uint8_t *const *bufs, const size_t *lens
     /* uploads and kernels in order on one stream; the state region is cleared there first */
     b->uploaded_async = false;
     b->decoded = false;
-    if (upload(b, prep, meta, state, nullptr, s)) return -1;
-    HIP_TRY(hipEventRecord(b->ev_up, s));
+    if (upload(b, prep.img, meta, state, nullptr, &s, 1, &b->n_up)) return -1;
+    HIP_TRY(hipEventRecord(b->ev_up[0], s));
     if (enqueue_decode(b, s)) return -1;
     if (view) *view = b;
     /* the caller's buffers and the descriptor mirror are free once the upload is through;
      * the kernels run on */
-    HIP_TRY(hipEventSynchronize(b->ev_up));
+    HIP_TRY(hipEventSynchronize(b->ev_up[0]));
     return 0;
 }
 

@@ -14,6 +14,7 @@
 #define MJ_ENTROPY_CORE_H
 
 #include <stdint.h>
+#include <string.h>
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -543,21 +544,33 @@ MJ_HD MjClass16 mj_classify16(const uint32_t (&w)[4], uint32_t prev, uint32_t ne
 }
 
 /* The classes of bytes pos .. pos + 15 of a segment of len bytes (pos a multiple of 16,
- * pos < len; sixteen bytes are readable at seg + pos).  Bytes at or past the end are
+ * pos < len; twenty bytes are readable from the last four-byte boundary at or before
+ * seg + pos).  The segment may start at any byte address.  Bytes at or past the end are
  * MJ_B_DROP and count as zero for their neighbours.  w gets the bytes. */
 MJ_HD MjClass16 mj_classify16_at(const uint8_t *seg, uint32_t len, uint32_t pos, uint32_t (&w)[4]) {
-    const uint32_t *p32 = reinterpret_cast<const uint32_t *>(seg + pos);
+    const uint8_t *at = seg + pos;
+    const uint32_t mis = (uint32_t) ((uintptr_t) at & 3u);
 #if defined(__HIP_DEVICE_COMPILE__)
-    const uint4 v = *reinterpret_cast<const uint4 *>(p32);
-    w[0] = v.x;
-    w[1] = v.y;
-    w[2] = v.z;
-    w[3] = v.w;
+    /* four-byte aligned loads (all the memory instructions ask for), then a byte shift */
+    struct __attribute__((aligned(4))) Quad4 {
+        uint32_t x, y, z, w;
+    };
+    const Quad4 v = *reinterpret_cast<const Quad4 *>(at - mis);
+    if (mis == 0) {
+        w[0] = v.x;
+        w[1] = v.y;
+        w[2] = v.z;
+        w[3] = v.w;
+    } else {
+        const uint32_t t = *reinterpret_cast<const uint32_t *>(at - mis + 16);
+        w[0] = __builtin_amdgcn_alignbyte(v.y, v.x, mis);
+        w[1] = __builtin_amdgcn_alignbyte(v.z, v.y, mis);
+        w[2] = __builtin_amdgcn_alignbyte(v.w, v.z, mis);
+        w[3] = __builtin_amdgcn_alignbyte(t, v.w, mis);
+    }
 #else
-    w[0] = p32[0];
-    w[1] = p32[1];
-    w[2] = p32[2];
-    w[3] = p32[3];
+    (void) mis;
+    memcpy(w, at, 16);
 #endif
     const uint32_t prev = pos ? seg[pos - 1] : 0u;
     const uint32_t next = (pos + 16 < len) ? seg[pos + 16] : 0u;

@@ -372,9 +372,44 @@ void mj_choose_split(uint64_t raw_len, uint32_t n_ivl, uint32_t *sub_bits, uint3
     *lane_subs = g;
 }
 
+/* Everything the Huffman set of a scan is built from, as bytes: the table selectors of
+ * the scan components and, for every table one of them names, the code counts and the
+ * symbols of the DHT segment.  Equal keys give equal sets. */
+size_t mj_huff_key(const MjParsed *p, uint8_t *key) {
+    const ScanHeader *sh = &p->sh;
+    size_t n = 0;
+    int used[TC_NUM][MAX_TABLES] = {{0}};
+    key[n++] = sh->nics;
+    for (int s = 0; s < sh->nics && s < 4; s++) {
+        key[n++] = sh->ics[s].dc;
+        key[n++] = sh->ics[s].ac;
+        if (sh->ics[s].dc < MAX_TABLES) used[TC_DC][sh->ics[s].dc] = 1;
+        if (sh->ics[s].ac < MAX_TABLES) used[TC_AC][sh->ics[s].ac] = 1;
+    }
+    for (int c = 0; c < TC_NUM; c++) {
+        for (int t = 0; t < MAX_TABLES; t++) {
+            if (!used[c][t]) continue;
+            const HuffTable *ht = &p->hts.DCAC[c][t];
+            size_t total = 0;
+            memcpy(key + n, ht->len, 16);
+            n += 16;
+            for (int l = 0; l < 16; l++) {
+                const size_t k = ht->symbols[l] ? ht->len[l] : 0;
+                if (total + k > 256) break;
+                if (k) memcpy(key + n, ht->symbols[l], k);
+                n += k;
+                total += k;
+            }
+        }
+    }
+    return n;
+}
+
 int mj_flatten_image(const MjParsed *p, size_t file_len, MjImageDev *img, MjHuffSet *set, const char **why) {
     memset(img, 0, sizeof *img);
-    memset(set, 0, sizeof *set);
+    /* set == NULL: the caller already holds the set of an image with the same key */
+    if (set) memset(set, 0, sizeof *set);
+    uint32_t nac = 0, ntab = 0;
     const FrameHeader *fh = &p->fh;
     const ScanHeader *sh = &p->sh;
     if (fh->precision != 8) {
@@ -435,17 +470,21 @@ int mj_flatten_image(const MjParsed *p, size_t file_len, MjImageDev *img, MjHuff
             return fail(why, "bad Huffman table selector");
         }
         if (ac_slot[ta] < 0) {
-            ac_slot[ta] = (int) set->nac++;
+            ac_slot[ta] = (int) nac++;
         }
     }
-    set->ntab = set->nac;
+    ntab = nac;
     for (int s = 0; s < sh->nics; s++) {
         int td = sh->ics[s].dc;
         if (dc_slot[td] < 0) {
-            dc_slot[td] = (int) set->ntab++;
+            dc_slot[td] = (int) ntab++;
         }
     }
-    for (int t = 0; t < 4; t++) {
+    if (set) {
+        set->nac = nac;
+        set->ntab = ntab;
+    }
+    for (int t = 0; t < 4 && set; t++) {
         if (ac_slot[t] >= 0) {
             mj_flatten_huff(&p->hts.DCAC[TC_AC][t], 1, &set->tab[ac_slot[t]], &set->walk[ac_slot[t]], &set->run[ac_slot[t]],
                             &set->next[ac_slot[t]]);

@@ -34,8 +34,14 @@ void mj_parsed_free(MjParsed *p);
 /* huff_table.h:9-14 -> lookup form. */
 void mj_flatten_huff(const HuffTable *ht, int is_ac, MjHuffDev *out, MjHuffWalk *walk, MjHuffRun *pair, MjHuffPair *next);
 
+/* What the Huffman set of the scan depends on, as at most MJ_HUFF_KEY_BYTES bytes (returns
+ * how many): images with equal keys share one set, and only the first needs it built. */
+#define MJ_HUFF_KEY_BYTES (16 + 8 * (16 + 256))
+size_t mj_huff_key(const MjParsed *p, uint8_t *key);
+
 /* Geometry, per-slot table selection, quantiser tables and the Huffman set of one
- * image.  Batch placement fields are left zero.  0 / -1. */
+ * image (set may be NULL when the caller already has the set for this image's key).
+ * Batch placement fields are left zero.  0 / -1. */
 int mj_flatten_image(const MjParsed *p, size_t file_len, MjImageDev *img, MjHuffSet *set, const char **why);
 
 /* How an entropy segment of raw_len bytes in n_ivl restart intervals is cut up:

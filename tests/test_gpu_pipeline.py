@@ -1,6 +1,9 @@
 """GPU: the pipelined front end (mj_pipe_*) against the one-shot path and the golden
-outputs: batches of different shapes pushed through a few slots, from pageable and from
-page-locked host memory; every image of every batch is checked."""
+outputs: batches of different shapes pushed through a few slots, from pageable memory
+(gathered in a staging buffer), from page-locked memory with the files back to back (one
+copy of the whole stretch; images are then read at whatever byte alignment they land on)
+and from page-locked memory in descending address order (one copy per image); every image
+of every batch is checked."""
 import hashlib
 
 import numpy as np
@@ -26,13 +29,13 @@ def _digest(b, i):
     return hashlib.sha256(b.coefs(i).tobytes()).hexdigest(), hashlib.sha256(b.rgb(i).tobytes()).hexdigest()
 
 
-@pytest.mark.parametrize("pinned", [False, True])
+@pytest.mark.parametrize("pinned", [False, True, "descending"])
 @pytest.mark.parametrize("depth", [2, 3])
 def test_pipeline_of_mixed_batches_equals_golden(ctx, depth, pinned):
     """Batches that differ in size, geometry and tables go through `depth` recycled slots;
     each slot is read before it is recycled.  Bit-exact against the reference's outputs."""
     fixtures = [load_fixture(n) for n in PARITY_FIXTURES]
-    rng = np.random.default_rng(depth * 2 + pinned)
+    rng = np.random.default_rng(depth * 2 + bool(pinned))
     pipe = ctx.pipe(depth, 0)
     inflight = []
     keep = []
@@ -49,7 +52,7 @@ def test_pipeline_of_mixed_batches_equals_golden(ctx, depth, pinned):
     for step in range(9):
         idx = list(rng.choice(len(fixtures), size=int(rng.integers(1, 12)), replace=True))
         files = [fixtures[k][0] for k in idx]
-        src = binding.PinnedFiles(files) if pinned else files
+        src = binding.PinnedFiles(files, descending=(pinned == "descending")) if pinned else files
         keep.append(src)
         if len(inflight) == depth:          # the slot about to be recycled
             check(inflight.pop(0))
