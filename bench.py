@@ -120,14 +120,22 @@ def _cpu_worker(args):
     return lib.time_decode(data, iters)
 
 
-def cpu_baseline(files, pixels, max_cores=16, seconds=10.0):
+# Workloads the compiled reference cannot be the checker or the CPU baseline for: C4 (its
+# 16-bit MCU counter misplaces blocks beyond 65,535 MCUs, decode.h:15) and C5 (at q95 with
+# restart markers it walks into the marker bytes and crashes: its restart check looks at
+# a partly consumed FF byte, bitstream.c:84-176).  The CPU restatement stands in.
+REFERENCE_UNUSABLE = ("C4", "C5")
+
+
+def cpu_baseline(files, pixels, workload, max_cores=16, seconds=10.0):
     """The reference (oracle/_ref, compiled from its unmodified sources) -- or, where
-    that library is absent, the CPU restatement -- timed headless on the host cores:
-    one process per core, each decoding its own image repeatedly (decode + colour, file
-    already in memory), about `seconds` of CPU work per core."""
+    that library is absent or cannot decode the workload, the CPU restatement -- timed
+    headless on the host cores: one process per core, each decoding its own image
+    repeatedly (decode + colour, file already in memory), about `seconds` of CPU work per
+    core."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from refbind import Oracle, Ref
-    kind = "reference" if Ref.available() else ("port" if Oracle.available() else None)
+    kind = "reference" if Ref.available() and workload not in REFERENCE_UNUSABLE[1:] else ("port" if Oracle.available() else None)
     if kind is None:
         return None
     try:
@@ -164,12 +172,11 @@ def _digest_worker(args):
 
 def checker_digests(files, workers, workload):
     """SHA-256 of the checker's coefficients and RGB for every file (forked workers: call
-    before the GPU is initialised).  The compiled reference where it is present and right
-    (its 16-bit MCU counter misplaces blocks beyond 65,535 MCUs, decode.h:15; its grey
-    colour step shears widths that are not multiples of 8), else the CPU restatement."""
+    before the GPU is initialised).  The compiled reference where it is present and can
+    decode the workload (see REFERENCE_UNUSABLE), else the CPU restatement."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from refbind import Oracle, Ref
-    if Ref.available() and workload != "C4":
+    if Ref.available() and workload not in REFERENCE_UNUSABLE:
         kind = "reference"
     elif Oracle.available():
         kind = "port"
@@ -322,7 +329,7 @@ def main():
     # the CPU legs also run before the GPU is initialised (their workers are plain forks)
     cpu_base = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu_base = cpu_baseline(files, px_img)
+        cpu_base = cpu_baseline(files, px_img, args.workload)
     checker, digests = (None, None)
     if args.parity != "none":
         n_check = len(files) if args.parity == "all" else 1

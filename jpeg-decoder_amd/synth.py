@@ -21,6 +21,9 @@ def _load():
         _lib.mjs_encode.restype = C.c_int64
         _lib.mjs_encode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                     C.c_void_p, C.c_size_t]
+        _lib.mjs_encode2.restype = C.c_int64
+        _lib.mjs_encode2.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_void_p, C.c_size_t]
     return _lib
 
 
@@ -39,9 +42,10 @@ def synth_image(width, height, seed, sigma=12.0, grey=False):
     return np.ascontiguousarray(out[..., 0]) if grey else out
 
 
-def encode_jpeg(pixels, sampling="4:2:0", quality=85, restart_interval=0):
+def encode_jpeg(pixels, sampling="4:2:0", quality=85, restart_interval=0, optimise=False):
     """Baseline SOF0 JPEG bytes for an (H, W, 3) RGB or (H, W) grey uint8 array.
-    restart_interval is in MCUs; 0 means no DRI segment."""
+    restart_interval is in MCUs; 0 means no DRI segment.  optimise: Huffman tables fitted
+    to the image (T.81 Annex K.2) instead of the Annex K typical tables."""
     lib = _load()
     a = np.ascontiguousarray(pixels, np.uint8)
     if a.ndim == 2:
@@ -53,8 +57,8 @@ def encode_jpeg(pixels, sampling="4:2:0", quality=85, restart_interval=0):
     cap = w * h * ncomp + (1 << 16)
     for _ in range(2):
         out = np.empty(cap, np.uint8)
-        n = lib.mjs_encode(a.ctypes.data, w, h, ncomp, hs, vs, int(quality), int(restart_interval),
-                           out.ctypes.data, cap)
+        n = lib.mjs_encode2(a.ctypes.data, w, h, ncomp, hs, vs, int(quality), int(restart_interval), 1 if optimise else 0,
+                            out.ctypes.data, cap)
         if n < 0:
             raise ValueError("mjs_encode: bad arguments")
         if n <= cap:

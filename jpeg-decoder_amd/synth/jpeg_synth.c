@@ -7,8 +7,10 @@
  *
  * Integer-only pipeline (fixed-point colour transform, exact integer DCT, integer
  * quantiser) so the same pixels give the same bytes on every machine.  Huffman
- * tables are the Annex K typical tables of ITU-T T.81; quantiser tables are the
- * Annex K tables under the usual 1..100 quality scaling.
+ * tables are the Annex K typical tables of ITU-T T.81 or, on request, tables fitted to
+ * the image (two passes: symbol histogram, then the code-length procedure of T.81
+ * Annex K.2 with its 16-bit limit); quantiser tables are the Annex K tables under the
+ * usual 1..100 quality scaling.
  */
 #include <math.h>
 #include <stdint.h>
@@ -125,13 +127,19 @@ static int nbits_of(int v) {
     return n;
 }
 
-static void enc_block(BW *w, const int16_t *q, int *pred, const EncTab *dc, const EncTab *ac) {
+/* One block's symbols.  With freq_dc / freq_ac set they are only counted (the first pass
+ * of an encode with fitted tables); otherwise they are written with the tables dc / ac. */
+static void enc_block(BW *w, const int16_t *q, int *pred, const EncTab *dc, const EncTab *ac, long *freq_dc, long *freq_ac) {
     int diff = q[0] - *pred;
     *pred = q[0];
     int s = nbits_of(diff);
-    bw_bits(w, dc->code[s], dc->len[s]);
-    if (s) {
-        bw_bits(w, (unsigned) (diff < 0 ? diff - 1 : diff), s);
+    if (freq_dc) {
+        freq_dc[s]++;
+    } else {
+        bw_bits(w, dc->code[s], dc->len[s]);
+        if (s) {
+            bw_bits(w, (unsigned) (diff < 0 ? diff - 1 : diff), s);
+        }
     }
     int run = 0;
     for (int k = 1; k < 64; k++) {
@@ -141,18 +149,97 @@ static void enc_block(BW *w, const int16_t *q, int *pred, const EncTab *dc, cons
             continue;
         }
         while (run > 15) {
-            bw_bits(w, ac->code[0xF0], ac->len[0xF0]);
+            if (freq_ac) freq_ac[0xF0]++;
+            else bw_bits(w, ac->code[0xF0], ac->len[0xF0]);
             run -= 16;
         }
         int sz = nbits_of(v);
         int rs = (run << 4) | sz;
-        bw_bits(w, ac->code[rs], ac->len[rs]);
-        bw_bits(w, (unsigned) (v < 0 ? v - 1 : v), sz);
+        if (freq_ac) {
+            freq_ac[rs]++;
+        } else {
+            bw_bits(w, ac->code[rs], ac->len[rs]);
+            bw_bits(w, (unsigned) (v < 0 ? v - 1 : v), sz);
+        }
         run = 0;
     }
     if (run) {
-        bw_bits(w, ac->code[0], ac->len[0]);
+        if (freq_ac) freq_ac[0]++;
+        else bw_bits(w, ac->code[0], ac->len[0]);
     }
+}
+
+/* T.81 Annex K.2: code lengths from symbol frequencies (Figure K.1), no code longer than
+ * 16 bits (Figure K.3), symbols sorted by length then value (Figure K.4).  A reserved
+ * 257th symbol of frequency 1 keeps the all-ones code word unused.  bits[l-1] = codes of
+ * length l; vals = the symbols in code order; returns how many. */
+static int fit_table(const long *freq_in, uint8_t *bits, uint8_t *vals) {
+    const int max_len = 16;
+    long freq[257];
+    int codesize[257], others[257];
+    int nbits[33];
+    for (int i = 0; i < 256; i++) freq[i] = freq_in[i];
+    freq[256] = 1;
+    for (int i = 0; i < 257; i++) {
+        codesize[i] = 0;
+        others[i] = -1;
+    }
+    for (;;) {
+        int c1 = -1, c2 = -1;
+        long v = 0;
+        for (int i = 0; i <= 256; i++) {            /* least frequency, largest symbol among equals */
+            if (freq[i] && (c1 < 0 || freq[i] <= v)) {
+                v = freq[i];
+                c1 = i;
+            }
+        }
+        v = 0;
+        for (int i = 0; i <= 256; i++) {
+            if (freq[i] && i != c1 && (c2 < 0 || freq[i] <= v)) {
+                v = freq[i];
+                c2 = i;
+            }
+        }
+        if (c2 < 0) break;
+        freq[c1] += freq[c2];
+        freq[c2] = 0;
+        codesize[c1]++;
+        while (others[c1] >= 0) {
+            c1 = others[c1];
+            codesize[c1]++;
+        }
+        others[c1] = c2;
+        codesize[c2]++;
+        while (others[c2] >= 0) {
+            c2 = others[c2];
+            codesize[c2]++;
+        }
+    }
+    memset(nbits, 0, sizeof nbits);
+    for (int i = 0; i <= 256; i++) {
+        if (codesize[i]) nbits[codesize[i] > 32 ? 32 : codesize[i]]++;
+    }
+    for (int i = 32; i > max_len; i--) {
+        while (nbits[i] > 0) {
+            int j = i - 2;
+            while (nbits[j] == 0) j--;
+            nbits[i] -= 2;
+            nbits[i - 1]++;
+            nbits[j + 1] += 2;
+            nbits[j]--;
+        }
+    }
+    int top = max_len;
+    while (nbits[top] == 0) top--;
+    nbits[top]--;                                   /* the reserved symbol's code */
+    for (int l = 1; l <= 16; l++) bits[l - 1] = (uint8_t) nbits[l];
+    int n = 0;
+    for (int l = 1; l <= 32; l++) {
+        for (int i = 0; i < 256; i++) {
+            if (codesize[i] == l) vals[n++] = (uint8_t) i;
+        }
+    }
+    return n;
 }
 
 /* Exact integer 2-D DCT-II of (sample-128), then divide by the quantiser step
@@ -220,11 +307,20 @@ static void put_dht(BW *w, int tc_th, const uint8_t *bits, const uint8_t *vals) 
  * hs, vs: luma sampling factors (chroma is 1x1): 1,1 = 4:4:4; 2,1 = 4:2:2;
  *         2,2 = 4:2:0; 1,2 = 4:4:0; 4,1 = 4:1:1.  Ignored for grey.
  * ri: restart interval in MCUs (0 = no DRI segment, no RST markers).
+ * flags: bit 0 = fit the Huffman tables to the image instead of using the Annex K ones.
  * Returns the number of bytes the stream needs; it is complete only if that is
  * <= cap.  Negative on bad arguments.
  */
+int64_t mjs_encode2(const uint8_t *pix, int W, int H, int ncomp, int hs, int vs, int quality, int ri, int flags,
+                    uint8_t *out, size_t cap);
+
 int64_t mjs_encode(const uint8_t *pix, int W, int H, int ncomp, int hs, int vs, int quality, int ri,
                    uint8_t *out, size_t cap) {
+    return mjs_encode2(pix, W, H, ncomp, hs, vs, quality, ri, 0, out, cap);
+}
+
+int64_t mjs_encode2(const uint8_t *pix, int W, int H, int ncomp, int hs, int vs, int quality, int ri, int flags,
+                    uint8_t *out, size_t cap) {
     if (!pix || W <= 0 || H <= 0 || W > 65535 || H > 65535 || (ncomp != 1 && ncomp != 3)) return -1;
     if (ncomp == 1) hs = vs = 1;
     if (hs < 1 || hs > 4 || vs < 1 || vs > 2 || ri < 0 || ri > 65535) return -1;
@@ -286,11 +382,67 @@ int64_t mjs_encode(const uint8_t *pix, int W, int H, int ncomp, int hs, int vs, 
     uint16_t qt[2][64];
     scale_qt(QL, quality, qt[0]);
     scale_qt(QC, quality, qt[1]);
+    /* quantised blocks of the whole scan, in scan order */
+    const int bpm = hs * vs + (ncomp == 3 ? 2 : 0);
+    const int64_t nm = (int64_t) mx * my;
+    int16_t *Q = (int16_t *) malloc((size_t) nm * bpm * 64 * sizeof(int16_t));
+    if (!Q || !Yp || (ncomp == 3 && (!Cb || !Cr))) {
+        free(Q);
+        free(Yp);
+        free(Cb);
+        free(Cr);
+        return -1;
+    }
+    {
+        int16_t *q = Q;
+        for (int my_i = 0; my_i < my; my_i++) {
+            for (int mx_i = 0; mx_i < mx; mx_i++) {
+                for (int v = 0; v < vs; v++) {
+                    for (int h = 0; h < hs; h++, q += 64) {
+                        fdct_quant(Yp + (size_t) (my_i * mcu_h + 8 * v) * PW + mx_i * mcu_w + 8 * h, PW, qt[0], q);
+                    }
+                }
+                if (ncomp == 3) {
+                    fdct_quant(Cb + (size_t) (my_i * 8) * CW + mx_i * 8, CW, qt[1], q);
+                    q += 64;
+                    fdct_quant(Cr + (size_t) (my_i * 8) * CW + mx_i * 8, CW, qt[1], q);
+                    q += 64;
+                }
+            }
+        }
+    }
+
+    uint8_t bits[4][16], vals[4][256];     /* DC luma, AC luma, DC chroma, AC chroma */
+    memcpy(bits[0], DCL_BITS, 16);
+    memcpy(vals[0], DC_VALS, sizeof DC_VALS);
+    memcpy(bits[1], ACL_BITS, 16);
+    memcpy(vals[1], ACL_VALS, sizeof ACL_VALS);
+    memcpy(bits[2], DCC_BITS, 16);
+    memcpy(vals[2], DC_VALS, sizeof DC_VALS);
+    memcpy(bits[3], ACC_BITS, 16);
+    memcpy(vals[3], ACC_VALS, sizeof ACC_VALS);
+    if (flags & 1) {
+        long freq[4][256];
+        memset(freq, 0, sizeof freq);
+        int pred[3] = {0, 0, 0};
+        const int16_t *q = Q;
+        for (int64_t m = 0; m < nm; m++) {
+            if (ri && m && (m % ri) == 0) pred[0] = pred[1] = pred[2] = 0;
+            for (int i = 0; i < hs * vs; i++, q += 64) enc_block(NULL, q, &pred[0], NULL, NULL, freq[0], freq[1]);
+            if (ncomp == 3) {
+                enc_block(NULL, q, &pred[1], NULL, NULL, freq[2], freq[3]);
+                q += 64;
+                enc_block(NULL, q, &pred[2], NULL, NULL, freq[2], freq[3]);
+                q += 64;
+            }
+        }
+        for (int t = 0; t < (ncomp == 3 ? 4 : 2); t++) fit_table(freq[t], bits[t], vals[t]);
+    }
     EncTab dcl, dcc, acl, acc;
-    build_enc(DCL_BITS, DC_VALS, &dcl);
-    build_enc(DCC_BITS, DC_VALS, &dcc);
-    build_enc(ACL_BITS, ACL_VALS, &acl);
-    build_enc(ACC_BITS, ACC_VALS, &acc);
+    build_enc(bits[0], vals[0], &dcl);
+    build_enc(bits[1], vals[1], &acl);
+    build_enc(bits[2], vals[2], &dcc);
+    build_enc(bits[3], vals[3], &acc);
 
     BW w = {out, 0, out ? cap : 0, 0, 0, 0};
     bw_byte(&w, 0xFF); bw_byte(&w, 0xD8);
@@ -308,11 +460,11 @@ int64_t mjs_encode(const uint8_t *pix, int W, int H, int ncomp, int hs, int vs, 
         bw_byte(&w, 2); bw_byte(&w, 0x11); bw_byte(&w, 1);
         bw_byte(&w, 3); bw_byte(&w, 0x11); bw_byte(&w, 1);
     }
-    put_dht(&w, 0x00, DCL_BITS, DC_VALS);
-    put_dht(&w, 0x10, ACL_BITS, ACL_VALS);
+    put_dht(&w, 0x00, bits[0], vals[0]);
+    put_dht(&w, 0x10, bits[1], vals[1]);
     if (ncomp == 3) {
-        put_dht(&w, 0x01, DCC_BITS, DC_VALS);
-        put_dht(&w, 0x11, ACC_BITS, ACC_VALS);
+        put_dht(&w, 0x01, bits[2], vals[2]);
+        put_dht(&w, 0x11, bits[3], vals[3]);
     }
     if (ri) {
         bw_byte(&w, 0xFF); bw_byte(&w, 0xDD); bw_u16(&w, 4); bw_u16(&w, ri);
@@ -326,37 +478,26 @@ int64_t mjs_encode(const uint8_t *pix, int W, int H, int ncomp, int hs, int vs, 
     bw_byte(&w, 0); bw_byte(&w, 63); bw_byte(&w, 0);
 
     int pred[3] = {0, 0, 0};
-    int16_t q[64];
-    int64_t nm = (int64_t) mx * my, m = 0;
+    const int16_t *q = Q;
     int rst = 0;
-    for (int my_i = 0; my_i < my; my_i++) {
-        for (int mx_i = 0; mx_i < mx; mx_i++, m++) {
-            if (ri && m && (m % ri) == 0) {
-                bw_flush(&w);
-                bw_byte(&w, 0xFF);
-                bw_byte(&w, 0xD0 + (rst++ & 7));
-                pred[0] = pred[1] = pred[2] = 0;
-            }
-            for (int v = 0; v < vs; v++) {
-                for (int h = 0; h < hs; h++) {
-                    const uint8_t *s = Yp + (size_t) (my_i * mcu_h + 8 * v) * PW + mx_i * mcu_w + 8 * h;
-                    fdct_quant(s, PW, qt[0], q);
-                    enc_block(&w, q, &pred[0], &dcl, &acl);
-                }
-            }
-            if (ncomp == 3) {
-                const uint8_t *sb = Cb + (size_t) (my_i * 8) * CW + mx_i * 8;
-                fdct_quant(sb, CW, qt[1], q);
-                enc_block(&w, q, &pred[1], &dcc, &acc);
-                const uint8_t *sr = Cr + (size_t) (my_i * 8) * CW + mx_i * 8;
-                fdct_quant(sr, CW, qt[1], q);
-                enc_block(&w, q, &pred[2], &dcc, &acc);
-            }
+    for (int64_t m = 0; m < nm; m++) {
+        if (ri && m && (m % ri) == 0) {
+            bw_flush(&w);
+            bw_byte(&w, 0xFF);
+            bw_byte(&w, 0xD0 + (rst++ & 7));
+            pred[0] = pred[1] = pred[2] = 0;
+        }
+        for (int i = 0; i < hs * vs; i++, q += 64) enc_block(&w, q, &pred[0], &dcl, &acl, NULL, NULL);
+        if (ncomp == 3) {
+            enc_block(&w, q, &pred[1], &dcc, &acc, NULL, NULL);
+            q += 64;
+            enc_block(&w, q, &pred[2], &dcc, &acc, NULL, NULL);
+            q += 64;
         }
     }
-    (void) nm;
     bw_flush(&w);
     bw_byte(&w, 0xFF); bw_byte(&w, 0xD9);
+    free(Q);
     free(Yp);
     free(Cb);
     free(Cr);

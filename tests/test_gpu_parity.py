@@ -425,3 +425,50 @@ def test_many_live_images_through_the_dropin_entry_points(ctx):
         assert np.array_equal(pixels.reshape(H, W, 3), g["rgb"])
         lib.free_img(img)
         lib.free_frame_header(C.byref(fh))
+
+
+@pytest.mark.parametrize("config", ["C2", "C3"])
+def test_full_batch_of_64_every_image_vs_oracle(ctx, config):
+    """The benchmark's batch at full size -- 64 images of BASELINE config 2 / 3 in one
+    batch -- with every image's coefficient blocks and RGB compared (SHA-256) against the
+    CPU restatement, which tests/test_oracle_vs_ref.py pins to the compiled reference at
+    these sizes."""
+    import multiprocessing as mp
+    from _workers import config_file_and_digests, pool_size
+    with mp.get_context("spawn").Pool(pool_size()) as pool:
+        items = pool.map(config_file_and_digests, [(config, 1000 + s) for s in range(64)], chunksize=1)
+    b = ctx.batch([it[0] for it in items], 0)
+    b.decode()
+    b.sync()
+    bad = []
+    for i, (_, dc, dr) in enumerate(items):
+        if b.status(i) != 0 or hashlib.sha256(b.coefs(i).tobytes()).hexdigest() != dc or \
+                hashlib.sha256(b.rgb(i).tobytes()).hexdigest() != dr:
+            bad.append(i)
+    b.close()
+    assert not bad, f"{config}: images {bad} differ from the restatement"
+
+
+C5_CASES = [(mode, q, opt) for mode in ("grey", "4:2:2", "4:2:0") for q in (50, 75, 95) for opt in (False, True)]
+
+
+def test_config5_mixed_batch_1080p_vs_oracle(ctx, oracle):
+    """BASELINE config 5 at 1920x1080: grey / 4:2:2 / 4:2:0 x q 50 / 75 / 95 x Annex K tables /
+    tables fitted to the image (T.81 Annex K.2), half of them with one restart
+    interval per MCU row, all in one batch; coefficients, planes and RGB bit-exact against the
+    CPU restatement.  (The compiled reference cannot check this mix: at q95 with restart markers
+    it runs into the marker bytes and crashes, bitstream.c:84-176; the q50 / q75 files without
+    markers are pinned to it in tests/test_oracle_vs_ref.py.)"""
+    files, wants = [], []
+    for k, (mode, q, opt) in enumerate(C5_CASES):
+        grey = mode == "grey"
+        img = J.synth.synth_image(1920, 1080, seed=500 + k, grey=grey)
+        samp = "4:4:4" if grey else mode
+        ri = J.synth.mcus_per_row(1920, samp, grey) if k % 2 else 0
+        files.append(J.synth.encode_jpeg(img, samp, q, ri, optimise=opt))
+        wants.append(oracle.decode(files[-1]))
+    b = ctx.batch(files, binding.MJ_WANT_PLANES)
+    b.decode()
+    for i, o in enumerate(wants):
+        _check_image(b, i, o.coefs, o.planes, o.rgb, f"C5 {C5_CASES[i]}")
+    b.close()
