@@ -161,11 +161,11 @@ int mj_batch_scan_end(mj_batch *b, int i, size_t *offset);
 
 /* Device pointers (valid until mj_batch_destroy). */
 void *mj_batch_device_rgb(const mj_batch *b);    /* uint8, image i at rgb_offset, rows of rgb_pitch; 3 bytes per pixel, 4 with MJ_OUT_RGBA */
-void *mj_batch_device_coefs(const mj_batch *b);  /* int16[64] per block, zigzag order, scan order */
+void *mj_batch_device_coefs(const mj_batch *b);  /* int16[64] per block in natural (row-major) order, blocks in scan order */
 
 /* Synchronous device-to-host copies for checking results. */
 int mj_batch_copy_rgb(mj_batch *b, int i, uint8_t *dst, size_t dst_pitch);
-int mj_batch_copy_coefs(mj_batch *b, int i, int16_t *dst);          /* n_blocks*64 */
+int mj_batch_copy_coefs(mj_batch *b, int i, int16_t *dst);          /* n_blocks*64, each block in zigzag order (what dequant_data_unit receives) */
 int mj_batch_copy_plane(mj_batch *b, int i, int comp, uint8_t *dst); /* plane_w*plane_h, needs MJ_WANT_PLANES */
 
 /* Accumulated kernel time since the last mj_batch_reset_timing, from HIP events

@@ -326,6 +326,13 @@ class Pipe:
             pass
 
 
+# natural (row-major) position of zigzag index k: the coefficient buffer in HBM holds blocks in
+# natural order, block[:, NATPOS] is the zigzag order that mj_batch_copy_coefs reports
+NATPOS = np.array([0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21,
+                   28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61,
+                   54, 47, 55, 62, 63])
+
+
 class Emu:
     """Host emulation of the entropy kernels' algorithm (libmjemu.so); CPU tests only."""
 
@@ -336,6 +343,14 @@ class Emu:
         self.lib.mj_emu_decode_coefs.restype = C.c_int64
         self.lib.mj_emu_decode_coefs.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_int64, C.c_uint32,
                                                  C.POINTER(C.c_int64)]
+
+    def ycbcr_row(self, y, cb, cr):
+        """The kernel's integer colour transform on n (Y, Cb, Cr) triples -> (n, 3) RGB."""
+        y, cb, cr = (np.ascontiguousarray(a, np.uint8) for a in (y, cb, cr))
+        out = np.zeros((y.size, 3), np.uint8)
+        self.lib.mj_emu_ycbcr_row.argtypes = [C.c_void_p] * 3 + [C.c_int, C.c_void_p]
+        self.lib.mj_emu_ycbcr_row(y.ctypes.data, cb.ctypes.data, cr.ctypes.data, y.size, out.ctypes.data)
+        return out
 
     def decode_coefs(self, data, n_blocks_cap, sub_bits=0, lane_subs=0):
         out = np.zeros((n_blocks_cap, 64), np.int16)

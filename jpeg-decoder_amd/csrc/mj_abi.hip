@@ -1047,7 +1047,16 @@ int mj_batch_copy_coefs(mj_batch *b, int i, int16_t *dst) {
     if (!b || !dst || i < 0 || i >= (int) b->img.size()) return set_err("mj_batch_copy_coefs: bad arguments");
     const MjImageDev &im = b->img[i];
     if (mj_batch_sync(b)) return -1;
-    HIP_TRY(hipMemcpy(dst, b->d.coefs + im.coef_off * 64, (size_t) im.n_mcu * im.bpm * 128, hipMemcpyDeviceToHost));
+    const size_t n_blocks = (size_t) im.n_mcu * im.bpm;
+    HIP_TRY(hipMemcpy(dst, b->d.coefs + im.coef_off * 64, n_blocks * 128, hipMemcpyDeviceToHost));
+    /* HBM holds the blocks in natural order; the caller gets them in zigzag order, as the
+     * reference hands them to dequant_data_unit (quant_table.c:131) */
+    static const uint8_t natpos[64] = MJ_NATPOS_INIT;
+    for (size_t k = 0; k < n_blocks; k++) {
+        int16_t *blk = dst + k * 64, t[64];
+        memcpy(t, blk, sizeof t);
+        for (int z = 0; z < 64; z++) blk[z] = t[natpos[z]];
+    }
     return 0;
 }
 

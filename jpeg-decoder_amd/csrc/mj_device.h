@@ -32,6 +32,11 @@
 #define MJ_LUT_LONG 0x0400u    /* code longer than MJ_LUT_BITS; low bits = second-level table */
 #define MJ_LUT_WALK 0x0200u    /* longer code that found no second-level table: canonical walk */
 
+/* natural (row-major) position of the coefficient with zigzag index k (quant_table.c:25-34) */
+#define MJ_NATPOS_INIT                                                                                                   \
+    {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6,  7,  14, 21, 28, \
+     35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63}
+
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define MJ_DEV_INLINE static inline __host__ __device__

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../host/mj_host.h"
+#include "mj_colour_core.h"
 #include "mj_entropy_core.h"
 
 namespace {
@@ -83,6 +84,30 @@ void mj_emu_classify16(const uint8_t *buf, uint32_t len, uint32_t pos, uint8_t *
     }
 }
 
+/* The integer colour transform of the IDCT + colour kernel (mj_colour_core.h), one pixel
+ * per (y, cb, cr) triple: out gets R, G, B per pixel, as the oracle's row functions do. */
+int mj_emu_ycbcr_row(const uint8_t *y, const uint8_t *cb, const uint8_t *cr, int n, uint8_t *out) {
+    static constexpr MjChromaTable tab = mj_chroma_table();
+    for (int i = 0; i < n; i++) {
+        const uint32_t px = mj_ycc_to_rgb(y[i], cb[i], cr[i], tab.t[cb[i]], tab.t[256 + cr[i]]);
+        out[3 * i] = (uint8_t) px;
+        out[3 * i + 1] = (uint8_t) (px >> 8);
+        out[3 * i + 2] = (uint8_t) (px >> 16);
+    }
+    return 0;
+}
+
+/* How many (Cb, Cr) pairs have the G-share sum of the pair whose G wraps: the kernel tells
+ * that pair by its sum, so the answer must be one. */
+int mj_emu_wrap_sum_pairs(void) {
+    constexpr int32_t want = mj_cb_term(MJ_WRAP_CB).g + mj_cr_term(MJ_WRAP_CR).g;
+    int n = 0;
+    for (uint32_t cb = 0; cb < 256; cb++) {
+        for (uint32_t cr = 0; cr < 256; cr++) n += (mj_cb_term(cb).g + mj_cr_term(cr).g == want);
+    }
+    return n;
+}
+
 /* the byte-at-a-time rule, for comparison */
 int mj_emu_classify(uint32_t prev, uint32_t cur, uint32_t next) {
     return mj_classify(prev, cur, next);
@@ -138,6 +163,8 @@ int64_t mj_emu_decode_coefs(const uint8_t *file, size_t len, int16_t *coefs, int
     cx.pairs = (const unsigned char *) set->run;
     cx.pair_stride = (uint32_t) sizeof(MjHuffRun);
     cx.coefs = coefs;
+    static const uint8_t natpos[64] = MJ_NATPOS_INIT;
+    cx.natpos = natpos;
     MjScanCtx wcx = cx;   /* the writing pass looks up second symbols, not runs */
     wcx.pairs = (const unsigned char *) set->next;
     wcx.pair_stride = (uint32_t) sizeof(MjHuffPair);
@@ -262,7 +289,9 @@ int64_t mj_emu_decode_coefs(const uint8_t *file, size_t len, int16_t *coefs, int
                     uint32_t fin_blk = 0;
                     mj_write_step(wcx, L, skip, blk, blk_end, d, buf, fin, fin_blk);
                     if (fin) {
-                        memcpy(coefs + (size_t) fin_blk * 64, buf, sizeof buf);
+                        /* the kernels leave blocks in natural order; this function reports them
+                         * in zigzag order, as the reference hands them to dequant_data_unit */
+                        for (int z = 0; z < 64; z++) coefs[(size_t) fin_blk * 64 + z] = buf[natpos[z]];
                         memset(buf, 0, sizeof buf);
                     }
                 }

@@ -47,7 +47,8 @@ struct MjScanCtx {
                                     MjHuffPair (second-symbol entries) for the writing pass */
     uint32_t pair_stride;        /* sizeof of that side table */
     uint32_t slotw0, slotw1, slotw2; /* mj_slot_desc() of slot i in byte i & 3 of word i >> 2 (separate members: never indexed) */
-    int16_t *coefs;              /* block 0 of the image; 64 int16 per block, zigzag order */
+    int16_t *coefs;              /* block 0 of the image; 64 int16 per block, natural (row-major) order */
+    const uint8_t *natpos;       /* [64] natural position of zigzag index k (LDS on the device) */
     uint32_t bpm;                /* blocks per MCU */
 };
 
@@ -429,7 +430,8 @@ MJ_HD void mj_decode_span(const MjScanCtx &cx, uint32_t &p, uint32_t &k, uint32_
 
 /*
  * One step of the writing pass of one lane.  The lane assembles the block it is in
- * inside blkbuf (64 int16, zero-filled by the caller) and reports `fin` when the
+ * inside blkbuf (64 int16 in natural order -- the de-zigzag of quant_table.c:131-152
+ * happens here, at the store -- zero-filled by the caller) and reports `fin` when the
  * block is complete and should be copied to block index fin_blk of the image.
  *
  * Ownership: a block belongs to the lane that decodes its DC symbol.  A lane whose
@@ -447,10 +449,10 @@ MJ_HD void mj_write_step(const MjScanCtx &cx, MjLane &L, bool &skip, uint32_t &b
     const MjSym s = mj_step<true>(cx, L, acc, ended, 0);
     const bool mine = !skip && blk < blk_end;
     if (s.store && mine) {
-        blkbuf[s.kpos] = (int16_t) s.val;
+        blkbuf[cx.natpos[s.kpos]] = (int16_t) s.val;
     }
     if (s.store2 && mine) {
-        blkbuf[s.kpos2] = (int16_t) s.val2;
+        blkbuf[cx.natpos[s.kpos2]] = (int16_t) s.val2;
     }
     fin = false;
     if (s.done) {

@@ -88,13 +88,22 @@ hipError_t mj_launch_idct_colour(const MjDeviceBatch &b, hipStream_t s);
 /* tile geometry of the IDCT kernel for one image (host + device) */
 #define MJ_IDCT_THREADS 512
 #define MJ_IDCT_MAX_BLOCKS 256
+/* The kernel keeps the samples of a tile in LDS, sixteen bits per sample: 128 bytes per
+ * block, and 16 bytes between MCUs so that the row reads of neighbouring threads fall on
+ * different banks.  Three workgroups share the 160 KiB of a compute unit. */
+#define MJ_IDCT_SAMPLE_BYTES 34304
+static inline __host__ __device__ uint32_t mj_idct_mcu_bytes(uint32_t bpm) {
+    return bpm * 128u + 16u;
+}
 /* MCUs per tile: at most MJ_IDCT_MAX_BLOCKS blocks (eight lanes work on a block, 64 blocks per pass). */
 static inline __host__ __device__ uint32_t mj_idct_tile_cap(uint32_t bpm, uint32_t hmax) {
     /* the colour stage numbers groups of four pixels of a tile row by thread: at most
      * MJ_IDCT_THREADS of them, i.e. a tile is at most 4 * MJ_IDCT_THREADS pixels wide */
     uint32_t tmax = MJ_IDCT_MAX_BLOCKS / bpm;
     const uint32_t wmax = (4u * MJ_IDCT_THREADS) / (8u * (hmax ? hmax : 1u));
+    const uint32_t smax = MJ_IDCT_SAMPLE_BYTES / mj_idct_mcu_bytes(bpm);
     if (tmax > wmax) tmax = wmax;
+    if (tmax > smax) tmax = smax;
     return tmax ? tmax : 1;
 }
 static inline __host__ __device__ uint32_t mj_idct_tiles_x(uint32_t mcus_x, uint32_t bpm, uint32_t hmax) {

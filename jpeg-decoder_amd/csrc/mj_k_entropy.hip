@@ -75,6 +75,9 @@ __device__ __forceinline__ uint32_t sub_end(uint32_t b0, uint32_t b1, uint32_t n
 
 extern __shared__ __align__(16) unsigned char s_dyn[];
 
+/* zigzag index -> natural position, for the kernels that store coefficients */
+__constant__ uint8_t c_natpos[64] = MJ_NATPOS_INIT;
+
 /* LDS carve-up shared by all entropy kernels:
  * [Huffman tables][16 slot words][DC accumulators: waves x 4 components x 64 lanes]... */
 __device__ __forceinline__ int32_t *lds_dc(const MjDeviceBatch &b) {
@@ -109,6 +112,7 @@ __device__ __forceinline__ MjScanCtx make_ctx(const MjDeviceBatch &b, const MjIm
     cx.pair_stride = runs ? (uint32_t) sizeof(MjHuffRun) : (uint32_t) sizeof(MjHuffPair);
     mj_ctx_slots(cx, im.bpm, im.blk_comp, im.blk_dc, im.blk_ac);
     cx.coefs = b.coefs + im.coef_off * 64;
+    cx.natpos = nullptr;    /* the kernels that store coefficients point it at their LDS copy */
     return cx;
 }
 
@@ -532,7 +536,9 @@ __global__ __launch_bounds__(TPB) void mj_k_entropy_write(MjDeviceBatch b) {
     const uint32_t seq0 = (grp - im.wg_first) * MJ_WG_SEQS + part * WAVES;
     if (seq0 >= n_seq) return;
     unsigned char *s_next = reinterpret_cast<unsigned char *>(s_list_lane + TPB);
+    __shared__ uint8_t s_natpos[64];
     load_tables(b, im, s_next, false);
+    if (threadIdx.x < 64) s_natpos[threadIdx.x] = c_natpos[threadIdx.x];
     {   /* zero the block buffers */
         uint4 *z = reinterpret_cast<uint4 *>(s_blk);
         for (uint32_t i = threadIdx.x; i < TPB * BLK_STRIDE / 16; i += TPB) z[i] = make_uint4(0, 0, 0, 0);
@@ -548,7 +554,8 @@ __global__ __launch_bounds__(TPB) void mj_k_entropy_write(MjDeviceBatch b) {
     const uint32_t first = b.seq_sub[im.seq_off + seq];
     const Geo g = interval_geo(b.ivl_start + im.ivl_off, iv, S, SQ);
     const uint32_t n = min(g.nsub - first, SQ);
-    const MjScanCtx cx = make_ctx(b, im, s_next, false);
+    MjScanCtx cx = make_ctx(b, im, s_next, false);
+    cx.natpos = s_natpos;
     /* the lane's subsequences: u0 .. u0 + cnt - 1 of the sequence */
     const uint32_t u0 = lane * G;
     const bool valid = u0 < n;
@@ -647,9 +654,12 @@ __global__ __launch_bounds__(TPB) void mj_k_entropy_serial(MjDeviceBatch b) {
     const uint32_t ii = blockIdx.x;
     const MjImageDev &im = b.img[ii];
     unsigned char *s_next = lds_after_dc(b, WAVES);
+    __shared__ uint8_t s_natpos[64];
     load_tables(b, im, s_next, false);
+    if (threadIdx.x < 64) s_natpos[threadIdx.x] = c_natpos[threadIdx.x];
     __syncthreads();
-    const MjScanCtx cx = make_ctx(b, im, s_next, false);
+    MjScanCtx cx = make_ctx(b, im, s_next, false);
+    cx.natpos = s_natpos;
     const uint32_t *ivl = b.ivl_start + im.ivl_off;
     const uint32_t n_blocks = im.n_mcu * im.bpm;
     for (uint32_t iv = threadIdx.x; iv < im.n_ivl; iv += TPB) {
@@ -665,8 +675,8 @@ __global__ __launch_bounds__(TPB) void mj_k_entropy_serial(MjDeviceBatch b) {
                 mj_refill(L);
                 const uint32_t at = blk;
                 const MjSym s = mj_step<true>(cx, L, acc, blk, 0);
-                if (s.store) cx.coefs[(uint64_t) at * 64 + s.kpos] = (int16_t) s.val;
-                if (s.store2) cx.coefs[(uint64_t) at * 64 + s.kpos2] = (int16_t) s.val2;
+                if (s.store) cx.coefs[(uint64_t) at * 64 + cx.natpos[s.kpos]] = (int16_t) s.val;
+                if (s.store2) cx.coefs[(uint64_t) at * 64 + cx.natpos[s.kpos2]] = (int16_t) s.val2;
             }
         }
         /* the stream ended before the interval's blocks did */

@@ -9,41 +9,52 @@
  *
  * Work decomposition: one workgroup per *tile* of T consecutive MCUs of one MCU
  * row.  In scan order those MCUs' blocks are contiguous in the coefficient buffer
- * (luma and chroma of the same pixels sit next to each other), so the tile is one
- * contiguous run of T*bpm*128 bytes:
- *   1. the workgroup copies it to LDS with 16-byte coalesced loads;
- *   2. eight lanes share one 8x8 block, 64 blocks per pass: lane r de-zigzags and
- *      dequantises row r (int16 wrap), runs the row butterfly, the eight lanes
- *      transpose through LDS, lane x runs the column butterfly, they transpose back,
- *      and lane r level-shifts, clamps, truncates and stores row r of the samples
- *      over the block's own coefficients.  A lane holds eight values, not sixty-four:
- *      the kernel runs at six wavefronts per SIMD instead of three, which is what
- *      keeps HBM busy while other wavefronts are in the butterflies;
- *   3. the workgroup walks the tile's pixel rows: nearest-neighbour chroma lookup,
- *      colour transform, clamp, and 12-byte (4-pixel) coalesced stores of RGB24.
+ * (luma and chroma of the same pixels sit next to each other), and the entropy stage
+ * leaves every block in natural order, so:
+ *   1. eight lanes share one 8x8 block, 64 blocks per pass: lane r loads row r (16 bytes;
+ *      the eight lanes of a block read one 128-byte line, all loads of a thread are
+ *      issued before the first is used), dequantises it (int16 wrap), runs the row
+ *      butterfly, the eight lanes transpose through LDS, lane x runs the column
+ *      butterfly, they transpose back, and lane r level-shifts, clamps, truncates and
+ *      stores row r of the samples to the tile's sample buffer in LDS, sixteen bits per
+ *      sample.  A lane holds eight values, not sixty-four: the kernel runs at six
+ *      wavefronts per SIMD, which is what keeps HBM busy while other wavefronts are in
+ *      the butterflies;
+ *   2. the workgroup walks the tile in patches of 8 x 2^v pixels: nearest-neighbour
+ *      chroma lookup, colour transform in packed 16-bit integers, saturating pack, and
+ *      24-byte coalesced stores of RGB24.
  *
- * Arithmetic follows the reference's rounding points exactly: float storage, double
- * constants, no fused multiply-add (the file is compiled with -ffp-contract=off),
- * truncating conversions.  Bound: HBM (2*S bytes of coefficients in + 3 bytes of RGB
- * out per pixel, S = samples per pixel); MFMA is not applicable (no dense
- * contraction at this precision).
+ * The IDCT arithmetic follows the reference's rounding points exactly: float storage,
+ * double constants, no fused multiply-add (the file is compiled with
+ * -ffp-contract=off), truncating conversions.  The colour transform is the integer form
+ * of mj_colour_core.h, equal to the reference's on all 2^24 triples.  Bound: HBM (2*S
+ * bytes of coefficients in + 3 bytes of RGB out per pixel, S = samples per pixel); MFMA
+ * is not applicable (no dense contraction at this precision).
  */
+#include "mj_colour_core.h"
 #include "mj_internal.h"
 
 namespace {
 
 constexpr int TPB = MJ_IDCT_THREADS;
+constexpr int GROUPS = TPB / 8;                /* blocks per pass */
 constexpr int MAXB = MJ_IDCT_MAX_BLOCKS;
-constexpr int COEF_STRIDE = 136;               /* bytes per block in LDS: 128 + 8, spreads the 2-byte de-zigzag reads over the banks */
+constexpr int PASSES = (MAXB + GROUPS - 1) / GROUPS;
 constexpr int TR_GROUP = 72;                   /* floats per 8x8 transpose buffer: 64 + 8, conflict-free strided access */
-constexpr int TR_BYTES = (TPB / 8) * TR_GROUP * 4;
-
-/* zigzag position of natural-order coefficient n (inverse of quant_table.c:25-34) */
-__constant__ uint8_t c_zzinv[64] = {0,  1,  5,  6,  14, 15, 27, 28, 2,  4,  7,  13, 16, 26, 29, 42, 3,  8,  12, 17, 25, 30,
-                                    41, 43, 9,  11, 18, 24, 31, 40, 44, 53, 10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38,
-                                    46, 51, 55, 60, 21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63};
+constexpr int TR_BYTES = GROUPS * TR_GROUP * 4;
+constexpr int SMP_BYTES = MJ_IDCT_SAMPLE_BYTES;
+constexpr uint32_t BLK_BYTES = 128;            /* a block of samples in LDS: 8 rows of 8 x 16 bits */
 
 typedef float f2 __attribute__((ext_vector_type(2)));
+typedef unsigned short us8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+
+/* both chroma tables (Cb terms, then Cr terms), copied to LDS by every workgroup */
+__device__ const MjChromaTable c_chroma = mj_chroma_table();
+
+/* the one sum of G shares that belongs to the chroma pair whose G wraps (with Y = 219);
+ * tests/test_oracle_vs_ref.py checks that no other pair has it */
+constexpr int32_t WRAP_GSUM = mj_cb_term(MJ_WRAP_CB).g + mj_cr_term(MJ_WRAP_CR).g;
 
 /* (float) (C * (double) x) -- a product with a double constant, rounded to double and
  * then to float, as the C source's mixed types imply -- without leaving single
@@ -77,55 +88,62 @@ __device__ __forceinline__ f2 mulc(f2 x, SplitConst c) {
  * and folded into the constants: the results are bit-identical and twelve
  * multiplies per butterfly disappear.  Products of one value with one constant go
  * through mulc; the two-term rotations keep the reference's double arithmetic. */
+/* D = (A[SA] + B[SB], A[SA] + B[SB]) with the B term of the low (NL) or high (NH) half
+ * negated: one packed add for a butterfly's sum and difference, operands taken from
+ * whichever half of a register pair they are in. */
+#define MJ_SUMDIFF(D, A, SA, B, SB, NL, NH)                                                                              \
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[" #SA "," #SB "] op_sel_hi:[" #SA "," #SB "] neg_lo:[0," #NL "] neg_hi:[0," #NH "]" \
+        : "=v"(D)                                                                                                        \
+        : "v"(A), "v"(B))
+
+/* In: the eight values as the pairs (d0, d4), (d1, d7), (d2, d6), (d3, d5).  Out: the pairs
+ * (d0, d7), (d1, d6), (d2, d5), (d3, d4) of the result -- throughout, values stay in the
+ * register pairs in which the packed instructions take and leave them. */
+struct Idct8Out {
+    f2 o07, o16, o25, o34;
+};
 template <bool FINAL>
-__device__ __forceinline__ void idct8(float &d0, float &d1, float &d2, float &d3, float &d4, float &d5, float &d6,
-                                      float &d7) {
+__device__ __forceinline__ Idct8Out idct8(f2 d04, f2 d17, f2 d26, f2 d35) {
     /* FINAL: the caller's next step is 0.25 * x + 128 (dct.c:192); the exact factor
      * 0.25 is folded into the last constant as well */
     constexpr SplitConst C = split_const(FINAL ? 0.25 * 0.707106781 : 0.707106781);
     constexpr double C2 = 2.0 * 0.707106781;
     static_assert(C2 == 1.414213562, "one split serves both constants");
     constexpr SplitConst S2 = split_const(C2);
-    const float t0 = mulc(d0, S2);
-    const float t1 = d4, t2 = d2, t3 = d6;
-    const f2 T56 = mulc((f2){d3, d5}, S2);               /* 2 t5, 2 t6 */
-    const float T4 = d1 - d7;                            /* 2 t4 */
-    const float T5 = T56.x, T6 = T56.y;
-    const float T7 = d1 + d7;                            /* 2 t7 */
+    /* (t0, t1) = (1.414213562 d0, d4): the second half multiplies by one */
+    const f2 t01 = __builtin_elementwise_fma((f2){S2.hi, 1.0f}, d04, (f2){S2.lo, 0.0f} * d04);
+    const f2 T56 = mulc(d35, S2);                        /* 2 t5, 2 t6 */
+    f2 T47, U01, U46, U57, W03, W12;
+    MJ_SUMDIFF(T47, d17, 0, d17, 1, 1, 0);               /* 2 t4 = d1 - d7, 2 t7 = d1 + d7 */
+    MJ_SUMDIFF(U01, t01, 0, t01, 1, 0, 1);               /* 2 u0 = t0 + t1, 2 u1 = t0 - t1 */
+    const double t2d = (double) d26.x, t3d = (double) d26.y;
+    f2 U23;
+    U23.x = (float) (C2 * (0.38268343236 * t2d + -0.92387953251 * t3d));   /* 2 u2 */
+    U23.y = (float) (C2 * (0.92387953251 * t2d + 0.38268343236 * t3d));    /* 2 u3 */
+    MJ_SUMDIFF(U46, T47, 0, T56, 1, 0, 1);               /* 4 u4 = T4 + T6, 4 u6 = T4 - T6 */
+    MJ_SUMDIFF(U57, T47, 1, T56, 0, 1, 0);               /* 4 u5 = T7 - T5, 4 u7 = T7 + T5 */
 
-    const float U0 = t0 + t1;                            /* 2 u0 */
-    const float U1 = t0 - t1;                            /* 2 u1 */
-    const double t2d = (double) t2, t3d = (double) t3;
-    const float U2 = (float) (C2 * (0.38268343236 * t2d + -0.92387953251 * t3d));   /* 2 u2 */
-    const float U3 = (float) (C2 * (0.92387953251 * t2d + 0.38268343236 * t3d));    /* 2 u3 */
-    const float U4 = T4 + T6;                            /* 4 u4 */
-    const float U5 = T7 - T5;                            /* 4 u5 */
-    const float U6 = T4 - T6;                            /* 4 u6 */
-    const float U7 = T5 + T7;                            /* 4 u7 */
-
-    const float W0 = U0 + U3;                            /* 4 w0 */
-    const float W1 = U1 + U2;
-    const float W2 = U1 - U2;
-    const float W3 = U0 - U3;
-    const double u4d = (double) U4, u5d = (double) U5, u6d = (double) U6, u7d = (double) U7;
-    const float W4 = (float) (0.8314696123 * u4d + -0.55557023302 * u7d);           /* 4 w4 */
-    const float W5 = (float) (0.9807852804 * u5d + -0.19509032201 * u6d);
-    const float W6 = (float) (0.19509032201 * u5d + 0.9807852804 * u6d);
-    const float W7 = (float) (0.55557023302 * u4d + 0.8314696123 * u7d);
+    MJ_SUMDIFF(W03, U01, 0, U23, 1, 0, 1);               /* 4 w0 = U0 + U3, 4 w3 = U0 - U3 */
+    MJ_SUMDIFF(W12, U01, 1, U23, 0, 0, 1);               /* 4 w1 = U1 + U2, 4 w2 = U1 - U2 */
+    const double u4d = (double) U46.x, u5d = (double) U57.x, u6d = (double) U46.y, u7d = (double) U57.y;
+    f2 W47, W56;
+    W47.x = (float) (0.8314696123 * u4d + -0.55557023302 * u7d);           /* 4 w4 */
+    W56.x = (float) (0.9807852804 * u5d + -0.19509032201 * u6d);
+    W56.y = (float) (0.19509032201 * u5d + 0.9807852804 * u6d);
+    W47.y = (float) (0.55557023302 * u4d + 0.8314696123 * u7d);
 
     /* reference: 1.414213562 * 2 * (w + w'); here the sum carries a factor 4 */
-    const f2 o07 = mulc((f2){W0, W0} + (f2){W7, -W7}, C);
-    const f2 o16 = mulc((f2){W1, W1} + (f2){W6, -W6}, C);
-    const f2 o25 = mulc((f2){W2, W2} + (f2){W5, -W5}, C);
-    const f2 o34 = mulc((f2){W3, W3} + (f2){W4, -W4}, C);
-    d0 = o07.x;
-    d1 = o16.x;
-    d2 = o25.x;
-    d3 = o34.x;
-    d4 = o34.y;
-    d5 = o25.y;
-    d6 = o16.y;
-    d7 = o07.y;
+    f2 s07, s16, s25, s34;
+    MJ_SUMDIFF(s07, W03, 0, W47, 1, 0, 1);
+    MJ_SUMDIFF(s16, W12, 0, W56, 1, 0, 1);
+    MJ_SUMDIFF(s25, W12, 1, W56, 0, 0, 1);
+    MJ_SUMDIFF(s34, W03, 1, W47, 0, 0, 1);
+    Idct8Out o;
+    o.o07 = mulc(s07, C);
+    o.o16 = mulc(s16, C);
+    o.o25 = mulc(s25, C);
+    o.o34 = mulc(s34, C);
+    return o;
 }
 
 /* dct.c:187-193 with CLAMP_8 (dct.c:6): clamp(0.25*x + 128) in double, then truncate.
@@ -133,84 +151,67 @@ __device__ __forceinline__ void idct8(float &d0, float &d1, float &d2, float &d3
  * that is not negative truncation is floor(q) + 128; a negative sum clamps to 0 either
  * way.  floor(q) + 128 is an integer, exact in float wherever it is inside [0, 255], and
  * the conversion instruction saturates to that range, so the double arithmetic reduces,
- * bit for bit, to a floor, an add and a saturating conversion -- which also places the
- * byte: the result is `word` with byte `pos` replaced by the sample. */
-__device__ __forceinline__ uint32_t finish(float q, uint32_t pos, uint32_t word) {
-    return __builtin_amdgcn_cvt_pk_u8_f32(floorf(q) + 128.0f, pos, word);
+ * bit for bit, to a floor, an add and a saturating conversion.  Two samples at a time:
+ * the result holds them as two 16-bit fields. */
+__device__ __forceinline__ uint32_t finish2(float qa, float qb) {
+    const f2 v = (f2){floorf(qa), floorf(qb)} + (f2){128.0f, 128.0f};
+    return __builtin_amdgcn_cvt_pk_u8_f32(v.y, 2, __builtin_amdgcn_cvt_pk_u8_f32(v.x, 0, 0));
 }
 
-/* colour_conversion.c:76-79 as compiled by gcc 11.4 -O2: below zero -> 0, above
- * 256 -> 255, otherwise truncate through a 32-bit integer (so exactly 256.0f, which
- * one (Y,Cb,Cr) triple reaches in G, wraps to 0).  Truncation of a value that is not
- * negative is floor, and the conversion saturates; the result replaces byte `pos` of
- * `word`. */
-__device__ __forceinline__ uint32_t store8(float v, uint32_t pos, uint32_t word) {
-    const uint32_t r = __builtin_amdgcn_cvt_pk_u8_f32(floorf(v), pos, word);
-    return (v == 256.0f) ? (word & ~(0xFFu << (8 * pos))) : r;
+/* D.byte[i] = byte sel.byte[i] of the eight bytes {lo: 0-3, hi: 4-7}; 0x0c gives 0x00, 0x0d gives 0xff */
+__device__ __forceinline__ uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) {
+    return __builtin_amdgcn_perm(hi, lo, sel);
 }
 
-/* colour_conversion.c:71-74, per chroma sample value, from per-workgroup LDS tables:
- *   cb -> g = 0.34414 * (cb - 128) in double, o = floor(1.772 * (cb - 128))
- *   cr -> g = 0.71414 * (cr - 128) in double, o = floor(1.402 * (cr - 128))
- * G keeps the reference's arithmetic: (y - g_cb) - g_cr in double, left to right,
- * rounded to float, truncated.  R = y + 1.402 (cr - 128) and B = y + 1.772 (cb - 128)
- * are an integer plus a multiple of 1/500 resp. 1/250: such a sum is never close enough
- * to an integer from below for the double or the float rounding to reach it, so
- * truncating the rounded sum equals y + floor(product) for every non-negative result,
- * and negative results clamp to 0 either way.  (Checked against the compiled reference
- * for all 65,536 (y, chroma) pairs per channel.) */
-struct __attribute__((aligned(16))) ChromaRow {
-    double g;
-    int32_t o;
-    int32_t pad_;
-};
-
-__device__ __forceinline__ int32_t floor_div(int32_t num, int32_t den) {   /* den > 0 */
-    const int32_t q = num / den;
-    return q - ((num % den != 0 && num < 0) ? 1 : 0);
+/* two signed 16-bit fields, each clamped to 0..255, as the two low bytes of the result */
+__device__ __forceinline__ uint32_t sat_pk(uint32_t v) {
+    uint32_t d;
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(d) : "v"(v));
+    return d;
 }
 
-__device__ __forceinline__ uint32_t ycc_to_rgb24(uint32_t Y, const ChromaRow tcb, const ChromaRow tcr) {
-    const double y = (double) Y;
-    const uint32_t R = (uint32_t) min(max((int32_t) Y + tcr.o, 0), 255);
-    const float G = (float) ((y - tcb.g) - tcr.g);
-    const uint32_t B = (uint32_t) min(max((int32_t) Y + tcb.o, 0), 255);
-    return store8(G, 1, R | (B << 16));
+/* {y.lo + o.lo, y.hi + o.lo}: two luma samples plus the one offset they share */
+__device__ __forceinline__ uint32_t add_pair_shared(uint32_t y, uint32_t o) {
+    uint32_t d;
+    asm("v_pk_add_u16 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(d) : "v"(y), "v"(o));
+    return d;
+}
+/* {y.lo + o.lo, y.hi + o.hi} */
+__device__ __forceinline__ uint32_t add_pair(uint32_t y, uint32_t o) {
+    uint32_t d;
+    asm("v_pk_add_u16 %0, %1, %2" : "=v"(d) : "v"(y), "v"(o));
+    return d;
 }
 
-/* 12-byte store of four RGB24 pixels (4-byte aligned) */
+/* Four pixels from their clamped channel pairs (r01 = R0 | R1 << 8 in its low half, ...) to
+ * `o`: twelve bytes of RGB24 (4-byte aligned), or sixteen of R, G, B, 255. */
 struct __attribute__((aligned(4))) Rgb4 {
     uint32_t a, b, c;
 };
-
-/* four pixels (0x00BBGGRR each) to `o`: twelve bytes of RGB24, or sixteen of R, G, B, 255 */
-__device__ __forceinline__ void store_quad(uint8_t *o, const uint32_t px[4], uint32_t gx, uint32_t X, bool rgba) {
+__device__ __forceinline__ void store4(uint8_t *o, uint32_t r01, uint32_t g01, uint32_t b01, uint32_t r23, uint32_t g23,
+                                       uint32_t b23, bool rgba) {
+    const uint32_t gb01 = perm(b01, g01, 0x05040100u);   /* G0 G1 B0 B1 */
+    const uint32_t rg23 = perm(g23, r23, 0x05040100u);   /* R2 R3 G2 G3 */
     if (rgba) {
-        if (gx + 4 <= X) {
-            *reinterpret_cast<uint4 *>(o) = make_uint4(px[0] | 0xFF000000u, px[1] | 0xFF000000u, px[2] | 0xFF000000u, px[3] | 0xFF000000u);
-        } else {
-#pragma unroll
-            for (uint32_t k = 0; k < 4; k++) {
-                if (gx + k < X) reinterpret_cast<uint32_t *>(o)[k] = px[k] | 0xFF000000u;
-            }
-        }
-        return;
-    }
-    if (gx + 4 <= X) {
-        Rgb4 v;
-        v.a = px[0] | (px[1] << 24);
-        v.b = (px[1] >> 8) | (px[2] << 16);
-        v.c = (px[2] >> 16) | (px[3] << 8);
-        *reinterpret_cast<Rgb4 *>(o) = v;
+        *reinterpret_cast<uint4 *>(o) = make_uint4(perm(gb01, r01, 0x0d060400u), perm(gb01, r01, 0x0d070501u),
+                                                   perm(rg23, b23, 0x0d000604u), perm(rg23, b23, 0x0d010705u));
     } else {
-#pragma unroll
-        for (uint32_t k = 0; k < 4; k++) {      /* constant indices: px stays in registers */
-            if (gx + k < X) {
-                o[3 * k] = (uint8_t) px[k];
-                o[3 * k + 1] = (uint8_t) (px[k] >> 8);
-                o[3 * k + 2] = (uint8_t) (px[k] >> 16);
-            }
-        }
+        Rgb4 v;
+        v.a = perm(gb01, r01, 0x01060400u);              /* R0 G0 B0 R1 */
+        v.b = perm(gb01, rg23, 0x02000705u);             /* G1 B1 R2 G2 */
+        v.c = perm(rg23, b23, 0x01070500u);              /* B2 R3 G3 B3 */
+        *reinterpret_cast<Rgb4 *>(o) = v;
+    }
+}
+
+/* pixel k of four (0x00BBGGRR each) to `o`, a byte at a time: edge pixels and the generic paths */
+__device__ __forceinline__ void store_px(uint8_t *o, uint32_t k, uint32_t px, bool rgba) {
+    if (rgba) {
+        reinterpret_cast<uint32_t *>(o)[k] = px | 0xFF000000u;
+    } else {
+        o[3 * k] = (uint8_t) px;
+        o[3 * k + 1] = (uint8_t) (px >> 8);
+        o[3 * k + 2] = (uint8_t) (px >> 16);
     }
 }
 
@@ -218,31 +219,38 @@ __device__ __forceinline__ void store_quad(uint8_t *o, const uint32_t px[4], uin
 #define MJ_IDCT_WAVES 6
 #endif
 
-/* Where the samples of the tile live after the butterflies: block `blk` of the tile
- * keeps its 8x8 bytes, row-major, in the first 64 bytes of its LDS slot. */
-__device__ __forceinline__ uint32_t sample_off(uint32_t blk, uint32_t x, uint32_t y) {
-    return __umul24(blk, COEF_STRIDE) + (y & 7u) * 8u + (x & 7u);
+/* Where the samples of the tile live after the butterflies: block `blk` of MCU `mcu` of
+ * the tile (blk counted over the whole tile) keeps its 8x8 samples row-major, sixteen
+ * bits each, at blk * 128 + mcu * 16. */
+__device__ __forceinline__ uint32_t sample_off(uint32_t mcu, uint32_t blk, uint32_t x, uint32_t y) {
+    return __umul24(blk, BLK_BYTES) + mcu * 16u + (y & 7u) * 16u + (x & 7u) * 2u;
 }
+
+struct TileGeo {
+    uint32_t bpm, s0, s1, s2;          /* blocks per MCU; first block slot of each component inside the MCU */
+    uint32_t tile_w, tile_h;           /* pixels */
+    uint32_t px0, py0;                 /* the tile's first pixel in the image */
+    uint32_t X, Y, pitch;
+    bool rgba;
+};
 
 /*
  * Colour stage for the common layouts: luma at full resolution, both chroma
  * components subsampled by 2^SH horizontally and 2^SV vertically with one block each
  * per MCU (4:4:4, 4:2:2, 4:2:0, 4:4:0, 4:1:1).  A thread converts a patch of
  * 8 x 2^SV pixels per step -- one row of a luma block per pixel row -- so every chroma
- * sample and its two table rows are fetched once per patch and the address arithmetic
- * is paid once per eight or sixteen pixels.  s0, s1, s2: first block slot of each
- * component inside the MCU.
+ * sample and its two table rows are fetched once per patch.  Per pair of pixels and
+ * channel: one packed 16-bit add of the two luma samples and the channel's offset, one
+ * saturating pack; byte permutes put four pixels' channels in RGB order.
  */
 template <int SH, int SV>
-__device__ __forceinline__ void colour_fast(const uint8_t *s_smp, const ChromaRow *s_tcb, const ChromaRow *s_tcr, uint32_t bpm,
-                                            uint32_t s0, uint32_t s1, uint32_t s2, uint32_t tile_w, uint32_t tile_h,
-                                            uint32_t px0, uint32_t py0, uint32_t X, uint32_t Y, uint32_t pitch,
-                                            uint8_t *rgb, bool rgba) {
-    const uint32_t bpp = rgba ? 4u : 3u;
-    constexpr int NC = 8 >> SH, HC = 4 >> SH, ROWS = 1 << SV;   /* chroma samples per patch row, per half of it */
-    const uint32_t cols = tile_w / 8, prow_n = tile_h >> SV;
+__device__ __forceinline__ void colour_fast(const uint8_t *s_smp, const MjChromaTerm *s_tab, const TileGeo &g, uint8_t *rgb) {
+    constexpr int NC = 8 >> SH, ROWS = 1 << SV;          /* chroma samples per patch row; pixel rows per patch */
+    constexpr int NCW = (NC + 1) / 2;                    /* words that hold them */
+    const uint32_t bpp = g.rgba ? 4u : 3u;
+    const uint32_t cols = g.tile_w / 8, prow_n = g.tile_h >> SV;
     const uint32_t dy = TPB / cols, dq = TPB - dy * cols;
-    uint8_t *rgb_tile = rgb + (uint64_t) py0 * pitch;
+    uint8_t *rgb_tile = rgb + (uint64_t) g.py0 * g.pitch;
     uint32_t pr = threadIdx.x / cols;
     uint32_t qx = threadIdx.x - pr * cols;
     for (; pr < prow_n; pr += dy, qx += dq) {
@@ -251,79 +259,101 @@ __device__ __forceinline__ void colour_fast(const uint8_t *s_smp, const ChromaRo
             pr++;
             if (pr >= prow_n) break;
         }
-        const uint32_t x = qx * 8, gx = px0 + x;
-        const uint32_t y = pr << SV, gy = py0 + y;
-        if (gy >= Y || gx >= X) continue;
+        const uint32_t x = qx * 8, gx = g.px0 + x;
+        const uint32_t y = pr << SV, gy = g.py0 + y;
+        if (gy >= g.Y || gx >= g.X) continue;
         /* chroma samples of the patch: chroma pixels (x >> SH ...) of row pr of MCU x >> (3 + SH) */
         const uint32_t cx = x >> SH, mcu = x >> (3 + SH);
-        const uint32_t mblk = __umul24(mcu, bpm);
-        const uint8_t *cbp = s_smp + sample_off(mblk + s1, cx, pr);
-        const uint8_t *crp = s_smp + sample_off(mblk + s2, cx, pr);
-        uint32_t cbw[2] = {0, 0}, crw[2] = {0, 0};
+        const uint32_t mblk = __umul24(mcu, g.bpm);
+        const uint8_t *cbp = s_smp + sample_off(mcu, mblk + g.s1, cx, pr);
+        const uint8_t *crp = s_smp + sample_off(mcu, mblk + g.s2, cx, pr);
+        uint32_t cbw[NCW], crw[NCW];
         if (NC == 8) {
-            const uint2 vb = *reinterpret_cast<const uint2 *>(cbp), vr = *reinterpret_cast<const uint2 *>(crp);
-            cbw[0] = vb.x;
-            cbw[1] = vb.y;
-            crw[0] = vr.x;
-            crw[1] = vr.y;
+            const uint4 vb = *reinterpret_cast<const uint4 *>(cbp), vr = *reinterpret_cast<const uint4 *>(crp);
+            cbw[0] = vb.x, cbw[1] = vb.y, cbw[2 % NCW] = vb.z, cbw[3 % NCW] = vb.w;
+            crw[0] = vr.x, crw[1] = vr.y, crw[2 % NCW] = vr.z, crw[3 % NCW] = vr.w;
         } else if (NC == 4) {
-            const uint32_t vb = *reinterpret_cast<const uint32_t *>(cbp), vr = *reinterpret_cast<const uint32_t *>(crp);
-            cbw[0] = vb & 0xFFFFu;
-            cbw[1] = vb >> 16;
-            crw[0] = vr & 0xFFFFu;
-            crw[1] = vr >> 16;
+            const uint2 vb = *reinterpret_cast<const uint2 *>(cbp), vr = *reinterpret_cast<const uint2 *>(crp);
+            cbw[0] = vb.x, cbw[1 % NCW] = vb.y;
+            crw[0] = vr.x, crw[1 % NCW] = vr.y;
         } else {
-            const uint32_t vb = *reinterpret_cast<const uint16_t *>(cbp), vr = *reinterpret_cast<const uint16_t *>(crp);
-            cbw[0] = vb & 0xFFu;
-            cbw[1] = vb >> 8;
-            crw[0] = vr & 0xFFu;
-            crw[1] = vr >> 8;
+            cbw[0] = *reinterpret_cast<const uint32_t *>(cbp);
+            crw[0] = *reinterpret_cast<const uint32_t *>(crp);
         }
-        /* luma block: column (x >> 3) & (2^SH - 1), row r >> 3 of the MCU's luma blocks */
+        /* luma block: column (x >> 3) & (2^SH - 1), row ly >> 3 of the MCU's luma blocks */
         const uint32_t lcol = (x >> 3) & ((1u << SH) - 1u);
-        uint2 yw[ROWS];
+        uint4 yw[ROWS];
 #pragma unroll
         for (int r = 0; r < ROWS; r++) {
             const uint32_t ly = y + r;
-            const uint32_t lblk = mblk + s0 + ((ly >> 3) << SH) + lcol;
-            yw[r] = *reinterpret_cast<const uint2 *>(s_smp + sample_off(lblk, 0, ly));
+            const uint32_t lblk = mblk + g.s0 + ((ly >> 3) << SH) + lcol;
+            yw[r] = *reinterpret_cast<const uint4 *>(s_smp + sample_off(mcu, lblk, 0, ly));
         }
+        /* per chroma sample: the three channel offsets */
+        uint32_t oR[NC], oG[NC], oB[NC];
+        bool wraps = false;
 #pragma unroll
-        for (int h = 0; h < 2; h++) {                   /* four pixels of every row at a time */
-            if (gx + 4 * h >= X) break;
-            ChromaRow tb[HC], tr[HC];
-#pragma unroll
-            for (int i = 0; i < HC; i++) {
-                tb[i] = s_tcb[(cbw[h] >> (8 * i)) & 0xFFu];
-                tr[i] = s_tcr[(crw[h] >> (8 * i)) & 0xFFu];
-            }
+        for (int i = 0; i < NC; i++) {
+            const uint32_t cb = (cbw[i >> 1] >> (16 * (i & 1))) & 0xFFFFu, cr = (crw[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
+            const MjChromaTerm tb = s_tab[cb], tr = s_tab[256 + cr];
+            const int32_t gs = tb.g + tr.g;
+            wraps |= (gs == WRAP_GSUM);
+            oR[i] = tr.o;
+            oG[i] = (uint32_t) (gs >> MJ_G_FRAC_BITS);
+            oB[i] = tb.o;
+        }
+        const bool whole = (gx + 8 <= g.X) && (gy + ROWS <= g.Y);
+        if (whole && !wraps) {
 #pragma unroll
             for (int r = 0; r < ROWS; r++) {
-                if (gy + r >= Y) break;
-                const uint32_t w = h ? yw[r].y : yw[r].x;
-                uint32_t px[4];
+                const uint32_t yp[4] = {yw[r].x, yw[r].y, yw[r].z, yw[r].w};   /* pixel pairs of the row */
+                uint32_t cr8[4], cg8[4], cb8[4];
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    px[k] = ycc_to_rgb24((w >> (8 * k)) & 0xFFu, tb[k >> SH], tr[k >> SH]);
+                for (int j = 0; j < 4; j++) {
+                    if (SH == 0) {
+                        cr8[j] = sat_pk(add_pair(yp[j], perm(oR[(2 * j + 1) % NC], oR[(2 * j) % NC], 0x05040100u)));
+                        cg8[j] = sat_pk(add_pair(yp[j], perm(oG[(2 * j + 1) % NC], oG[(2 * j) % NC], 0x05040100u)));
+                        cb8[j] = sat_pk(add_pair(yp[j], perm(oB[(2 * j + 1) % NC], oB[(2 * j) % NC], 0x05040100u)));
+                    } else {
+                        const int i = (2 * j) >> SH;
+                        cr8[j] = sat_pk(add_pair_shared(yp[j], oR[i]));
+                        cg8[j] = sat_pk(add_pair_shared(yp[j], oG[i]));
+                        cb8[j] = sat_pk(add_pair_shared(yp[j], oB[i]));
+                    }
                 }
                 /* rows of one tile are at most a few megabytes apart: 32-bit offsets from the
                  * tile's first row */
-                store_quad(rgb_tile + (__umul24(y + r, pitch) + bpp * (gx + 4 * h)), px, gx + 4 * h, X, rgba);
+                uint8_t *o = rgb_tile + (__umul24(y + r, g.pitch) + bpp * gx);
+                store4(o, cr8[0], cg8[0], cb8[0], cr8[1], cg8[1], cb8[1], g.rgba);
+                store4(o + 4 * bpp, cr8[2], cg8[2], cb8[2], cr8[3], cg8[3], cb8[3], g.rgba);
+            }
+        } else {
+            /* patches cut by the image edge, and the one chroma pair for which a luma value
+             * exists that wraps G (colour_conversion.c:78): pixel by pixel */
+            for (uint32_t r = 0; r < (uint32_t) ROWS && gy + r < g.Y; r++) {
+                const uint32_t ly = y + r;
+                const uint32_t lblk = mblk + g.s0 + ((ly >> 3) << SH) + lcol;
+                uint8_t *o = rgb_tile + (__umul24(ly, g.pitch) + bpp * gx);
+                for (uint32_t k = 0; k < 8 && gx + k < g.X; k++) {
+                    const uint32_t Y = *reinterpret_cast<const uint16_t *>(s_smp + sample_off(mcu, lblk, k, ly));
+                    const uint32_t cb = *reinterpret_cast<const uint16_t *>(cbp + 2 * (k >> SH));
+                    const uint32_t cr = *reinterpret_cast<const uint16_t *>(crp + 2 * (k >> SH));
+                    store_px(o + 4 * bpp * (k >> 2), k & 3u, mj_ycc_to_rgb(Y, cb, cr, s_tab[cb], s_tab[256 + cr]), g.rgba);
+                }
             }
         }
     }
 }
 
 __global__ __launch_bounds__(TPB, MJ_IDCT_WAVES) void mj_k_idct_colour(MjDeviceBatch b) {
-    /* LDS: the tile's blocks (coefficients, then -- in place -- samples); the transpose
-     * buffers of the butterflies, which later hold the two chroma product tables; the
-     * quantiser tables */
-    __shared__ __align__(16) uint8_t s_blk[MAXB * COEF_STRIDE];
+    /* LDS: the tile's samples; the transpose buffers of the butterflies, which later hold
+     * the two chroma tables; the quantiser table of every block slot of the MCU */
+    __shared__ __align__(16) uint8_t s_smp[SMP_BYTES];
     __shared__ __align__(16) uint8_t s_tr[TR_BYTES];
-    __shared__ __align__(16) uint16_t s_qt[MJ_MAX_COMP][64];
-    ChromaRow *s_tcb = reinterpret_cast<ChromaRow *>(s_tr);
-    ChromaRow *s_tcr = s_tcb + 256;
-    static_assert(2 * 256 * sizeof(ChromaRow) <= TR_BYTES, "chroma tables reuse the transpose buffers");
+    __shared__ __align__(16) uint16_t s_qt[MJ_MAX_BPM + 2][64];
+    MjChromaTerm *s_tab = reinterpret_cast<MjChromaTerm *>(s_tr);
+    static_assert(sizeof(MjChromaTable) <= TR_BYTES, "the chroma tables reuse the transpose buffers");
+    static_assert(sizeof(MjChromaTable) == TPB * sizeof(MjChromaTerm), "one table row per thread");
 
     const uint32_t ii = b.idct_wg_img[blockIdx.x];
     const MjImageDev &im = b.img[ii];
@@ -336,103 +366,89 @@ __global__ __launch_bounds__(TPB, MJ_IDCT_WAVES) void mj_k_idct_colour(MjDeviceB
     const uint32_t nm = min(T, im.mcus_x - m0);     /* MCUs in this tile */
     const uint32_t nblk = nm * bpm;
 
-    /* ---- 1. coefficients of the tile -> LDS (coalesced 16-byte loads) ------ */
-    const uint4 *src = reinterpret_cast<const uint4 *>(b.coefs + (im.coef_off + ((uint64_t) mrow * im.mcus_x + m0) * bpm) * 64);
-    for (uint32_t i = threadIdx.x; i < nblk * 8; i += TPB) {
-        const uint4 v = src[i];
-        uint2 *d = reinterpret_cast<uint2 *>(s_blk + (i >> 3) * COEF_STRIDE + (i & 7) * 16);
-        d[0] = make_uint2(v.x, v.y);
-        d[1] = make_uint2(v.z, v.w);
+    /* ---- 1. eight lanes per block, 64 blocks per pass ---------------------- */
+    const uint32_t r = threadIdx.x & 7u;                 /* the lane's row, then column, then row again */
+    const uint32_t grp = threadIdx.x >> 3;               /* block within the pass */
+    /* row r of every block this lane works on: the tile is one contiguous run of 16-byte rows */
+    const u4 *src = reinterpret_cast<const u4 *>(b.coefs + (im.coef_off + ((uint64_t) mrow * im.mcus_x + m0) * bpm) * 64);
+    u4 cv[PASSES];
+#pragma unroll
+    for (int p = 0; p < PASSES; p++) {
+        cv[p] = (u4){0, 0, 0, 0};
+        if (p * GROUPS + grp < nblk) cv[p] = __builtin_nontemporal_load(src + p * TPB + threadIdx.x);
     }
-    for (uint32_t i = threadIdx.x; i < im.ncs * 64; i += TPB) {
-        s_qt[i >> 6][i & 63] = im.qt[i >> 6][i & 63];
+    for (uint32_t i = threadIdx.x; i < bpm * 64; i += TPB) {
+        s_qt[i >> 6][i & 63] = im.qt[im.blk_comp[i >> 6]][i & 63];
     }
     __syncthreads();
 
-    /* ---- 2. eight lanes per block, 64 blocks per pass ---------------------- */
     if (!(MJ_DBG(b) & 16u)) {
-        const uint32_t r = threadIdx.x & 7u;                 /* the lane's row, then column, then row again */
-        const uint32_t grp = threadIdx.x >> 3;               /* block within the pass */
         float *tr = reinterpret_cast<float *>(s_tr) + grp * TR_GROUP;
-        /* zigzag positions of the coefficients of row r */
-        const uint2 zr = reinterpret_cast<const uint2 *>(c_zzinv)[r];
         /* the reference scales the first row and the first column by 1/sqrt(2) before the
          * butterflies (dct.c:164-167), the corner twice: lane 0 scales its whole row, the
          * others multiply by one, which changes nothing */
         constexpr SplitConst RS = split_const(0.707106781);
         const SplitConst row_scale = {(r == 0) ? RS.hi : 1.0f, (r == 0) ? RS.lo : 0.0f};
-        uint32_t slot = grp % bpm;                           /* block slot inside the MCU, kept up incrementally */
-        const uint32_t slot_step = (TPB / 8) % bpm;
-        for (uint32_t b0 = 0; b0 < nblk; b0 += TPB / 8, slot += slot_step) {
-            const uint32_t blk = b0 + grp;
+        const float rcp_bpm = 1.0f / (float) bpm;
+        /* where element j of a row sits after the row butterfly: 0 7 1 6 2 5 3 4 hold positions 0..7 */
+        const uint32_t tpos = (r < 4) ? 2 * r : 15 - 2 * r;
+#pragma unroll
+        for (int p = 0; p < PASSES; p++) {
+            const uint32_t blk = p * GROUPS + grp;
             if (blk >= nblk) continue;                       /* whole groups of eight lanes drop out together */
-            slot = (slot >= bpm) ? slot - bpm : slot;
-            const uint32_t comp = im.blk_comp[slot];
-            uint8_t *bp = s_blk + __umul24(blk, COEF_STRIDE);
+            /* blk + 0.5 over bpm is at least 0.05 away from an integer: the rounding of the
+             * reciprocal and of the product cannot reach one */
+            const uint32_t mcu = (uint32_t) (((float) blk + 0.5f) * rcp_bpm);
+            const uint32_t slot = blk - mcu * bpm;
             float c[8];
             {
-                const uint4 qv = *reinterpret_cast<const uint4 *>(&s_qt[comp][8 * r]);
-                const uint32_t qw[4] = {qv.x, qv.y, qv.z, qv.w};
+                /* int16 wrap of the product (quant_table.c:137): the low halves of the 16-bit products */
+                const us8 q = *reinterpret_cast<const us8 *>(&s_qt[slot][8 * r]);
+                const us8 z = __builtin_bit_cast(us8, cv[p]);
+                const us8 zq = z * q;
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const uint32_t zi = (((j < 4) ? zr.x : zr.y) >> (8 * (j & 3))) & 0xFFu;
-                    const int32_t z = *reinterpret_cast<const int16_t *>(bp + 2 * zi);
-                    const int32_t q = (int32_t) ((j & 1) ? (qw[j >> 1] >> 16) : (qw[j >> 1] & 0xFFFFu));
-                    /* int16 wrap of the product (quant_table.c:137) */
-                    c[j] = (float) (int16_t) (z * q);
-                }
+                for (int j = 0; j < 8; j++) c[j] = (float) (int16_t) zq[j];
             }
             c[0] = mulc(c[0], RS);                           /* first column */
-#pragma unroll
-            for (int j = 0; j < 8; j += 2) {                 /* first row */
-                const f2 v = mulc((f2){c[j], c[j + 1]}, row_scale);
-                c[j] = v.x;
-                c[j + 1] = v.y;
-            }
-            idct8<false>(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]);
+            /* first row, two values at a time; c[3] and c[5] together, as the butterfly takes them */
+            const f2 c04 = mulc((f2){c[0], c[4]}, row_scale), c17 = mulc((f2){c[1], c[7]}, row_scale);
+            const f2 c26 = mulc((f2){c[2], c[6]}, row_scale), c35 = mulc((f2){c[3], c[5]}, row_scale);
+            const Idct8Out ro = idct8<false>(c04, c17, c26, c35);
             /* rows -> columns (the reference transposes, runs rows again, and transposes
              * back on the store: dct.c:173-193).  The eight lanes of a block sit in one
-             * wavefront, which runs its LDS operations in order. */
-            *reinterpret_cast<float4 *>(tr + r * 8) = make_float4(c[0], c[1], c[2], c[3]);
-            *reinterpret_cast<float4 *>(tr + r * 8 + 4) = make_float4(c[4], c[5], c[6], c[7]);
+             * wavefront, which runs its LDS operations in order.  A row is stored in the
+             * order the butterfly leaves it: 0 7 1 6 2 5 3 4. */
+            *reinterpret_cast<f2 *>(tr + r * 8) = ro.o07;
+            *reinterpret_cast<f2 *>(tr + r * 8 + 2) = ro.o16;
+            *reinterpret_cast<f2 *>(tr + r * 8 + 4) = ro.o25;
+            *reinterpret_cast<f2 *>(tr + r * 8 + 6) = ro.o34;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int y = 0; y < 8; y++) c[y] = tr[y * 8 + r];
-            idct8<true>(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]);
+            const float *col = tr + tpos;                    /* element r of every row */
+            const Idct8Out co = idct8<true>((f2){col[0], col[4 * 8]}, (f2){col[1 * 8], col[7 * 8]}, (f2){col[2 * 8], col[6 * 8]},
+                                            (f2){col[3 * 8], col[5 * 8]});
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int y = 0; y < 8; y++) tr[y * 8 + r] = c[y];
+            tr[0 * 8 + r] = co.o07.x;
+            tr[7 * 8 + r] = co.o07.y;
+            tr[1 * 8 + r] = co.o16.x;
+            tr[6 * 8 + r] = co.o16.y;
+            tr[2 * 8 + r] = co.o25.x;
+            tr[5 * 8 + r] = co.o25.y;
+            tr[3 * 8 + r] = co.o34.x;
+            tr[4 * 8 + r] = co.o34.y;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             const float4 lo4 = *reinterpret_cast<const float4 *>(tr + r * 8), hi4 = *reinterpret_cast<const float4 *>(tr + r * 8 + 4);
-            const uint32_t lo = finish(lo4.w, 3, finish(lo4.z, 2, finish(lo4.y, 1, finish(lo4.x, 0, 0))));
-            const uint32_t hi = finish(hi4.w, 3, finish(hi4.z, 2, finish(hi4.y, 1, finish(hi4.x, 0, 0))));
-            /* row r of the samples, over the block's own coefficients: all eight lanes
-             * have read theirs by now */
-            *reinterpret_cast<uint2 *>(bp + r * 8) = make_uint2(lo, hi);
+            /* row r of the samples */
+            *reinterpret_cast<uint4 *>(s_smp + sample_off(mcu, blk, 0, r)) =
+                make_uint4(finish2(lo4.x, lo4.y), finish2(lo4.z, lo4.w), finish2(hi4.x, hi4.y), finish2(hi4.z, hi4.w));
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
     }
     __syncthreads();   /* all samples are in place; the transpose buffers are free */
-    {
-        const int32_t vi = (int32_t) (threadIdx.x & 255u) - 128;
-        const double v = (double) vi;
-        ChromaRow row;
-        row.pad_ = 0;
-        if (threadIdx.x < 256) {
-            row.g = 0.34414 * v;
-            row.o = floor_div(443 * vi, 250);    /* 1.772 */
-            s_tcb[threadIdx.x] = row;
-        } else {
-            row.g = 0.71414 * v;
-            row.o = floor_div(701 * vi, 500);    /* 1.402 */
-            s_tcr[threadIdx.x - 256] = row;
-        }
-    }
-    const uint8_t *s_smp = s_blk;
+    s_tab[threadIdx.x] = c_chroma.t[threadIdx.x];
 
     /* first block slot of each component inside the MCU (scan order: all blocks of a
      * component are consecutive, decode.c:591-611) */
@@ -447,7 +463,7 @@ __global__ __launch_bounds__(TPB, MJ_IDCT_WAVES) void mj_k_idct_colour(MjDeviceB
     /* sample (x, y) of component c, in tile coordinates of that component */
     auto smp = [&](uint32_t sb, uint32_t hs, uint32_t x, uint32_t y) -> uint32_t {
         const uint32_t bx = x >> 3, m = bx / hs, h = bx - m * hs;
-        return sample_off(m * bpm + sb + (y >> 3) * hs + h, x, y);
+        return *reinterpret_cast<const uint16_t *>(s_smp + sample_off(m, m * bpm + sb + (y >> 3) * hs + h, x, y));
     };
     __syncthreads();
 
@@ -460,58 +476,83 @@ __global__ __launch_bounds__(TPB, MJ_IDCT_WAVES) void mj_k_idct_colour(MjDeviceB
             const uint32_t hs = im.comp[cc].hsf, vs = im.comp[cc].vsf;
             const uint64_t py = (uint64_t) mrow * vs * 8 + im.blk_v[slot] * 8u + row;
             const uint64_t px = ((uint64_t) (m0 + m) * hs + im.blk_h[slot]) * 8;
+            const uint4 v = *reinterpret_cast<const uint4 *>(s_smp + sample_off(m, blk, 0, row));
             *reinterpret_cast<uint2 *>(b.planes + im.comp[cc].plane_off + py * im.comp[cc].pw + px) =
-                *reinterpret_cast<const uint2 *>(s_smp + blk * COEF_STRIDE + row * 8);
+                make_uint2(perm(v.y, v.x, 0x06040200u), perm(v.w, v.z, 0x06040200u));
         }
     }
 
     if (MJ_DBG(b) & 8u) return;
-    /* ---- 3. upsample + colour, 4 pixels (12 bytes) per thread per step ----- */
-    /* The tile's quads (4 horizontally adjacent pixels) are numbered row-major; a
-     * thread takes quad tid, tid + TPB, ... and tracks (row, quad-in-row)
-     * incrementally, so the loop has no division. */
-    const uint32_t tile_w = nm * im.hmax * 8, tile_h = im.vmax * 8;
-    const uint32_t px0 = m0 * im.hmax * 8, py0 = mrow * tile_h;
-    const uint32_t quads = tile_w / 4;
+    /* ---- 2. upsample + colour ---------------------------------------------- */
+    TileGeo g;
+    g.bpm = bpm;
+    g.s0 = sb0;
+    g.s1 = sb1;
+    g.s2 = sb2;
+    g.tile_w = nm * im.hmax * 8;
+    g.tile_h = im.vmax * 8;
+    g.px0 = m0 * im.hmax * 8;
+    g.py0 = mrow * g.tile_h;
+    g.X = im.X;
+    g.Y = im.Y;
+    g.pitch = im.pitch;
+    g.rgba = b.rgba != 0;
+    uint8_t *rgb = b.rgb + im.rgb_off;
+    const uint32_t bpp = g.rgba ? 4u : 3u;
+    /* The generic paths number the tile's quads (4 horizontally adjacent pixels) row-major;
+     * a thread takes quad tid, tid + TPB, ... and tracks (row, quad-in-row) incrementally,
+     * so the loop has no division. */
+    const uint32_t quads = g.tile_w / 4;
     const uint32_t dy = TPB / quads, dq = TPB - dy * quads;
     uint32_t y = threadIdx.x / quads;
     uint32_t qx = threadIdx.x - y * quads;
-    uint8_t *rgb = b.rgb + im.rgb_off;
-    const bool rgba = b.rgba != 0;
-    const uint32_t bpp = rgba ? 4u : 3u;
     if (im.ncs == 1) {
-        for (; y < tile_h; y += dy, qx += dq) {
+        for (; y < g.tile_h; y += dy, qx += dq) {
             if (qx >= quads) {
                 qx -= quads;
                 y++;
-                if (y >= tile_h) break;
+                if (y >= g.tile_h) break;
             }
-            const uint32_t x = qx * 4, gy = py0 + y, gx = px0 + x;
+            const uint32_t x = qx * 4, gy = g.py0 + y, gx = g.px0 + x;
             if (gy >= im.Y || gx >= im.X) continue;
-            const uint32_t v = *reinterpret_cast<const uint32_t *>(s_smp + smp(sb0, hs0, x, y));
-            const uint32_t a = v & 0xFF, bb = (v >> 8) & 0xFF, cc = (v >> 16) & 0xFF, d = v >> 24;
-            const uint32_t px[4] = {a * 0x010101u, bb * 0x010101u, cc * 0x010101u, d * 0x010101u};
-            store_quad(rgb + (uint64_t) gy * im.pitch + bpp * gx, px, gx, im.X, rgba);
+            const uint32_t bx = x >> 3, m = bx / hs0, h = bx - m * hs0;
+            const uint2 v = *reinterpret_cast<const uint2 *>(s_smp + sample_off(m, m * bpm + sb0 + (y >> 3) * hs0 + h, x, y));
+            uint8_t *o = rgb + (uint64_t) gy * im.pitch + bpp * gx;
+            if (gx + 4 <= im.X) {
+                if (g.rgba) {
+                    *reinterpret_cast<uint4 *>(o) = make_uint4(perm(0, v.x, 0x0d000000u), perm(0, v.x, 0x0d020202u),
+                                                               perm(0, v.y, 0x0d000000u), perm(0, v.y, 0x0d020202u));
+                } else {
+                    Rgb4 w;
+                    w.a = perm(0, v.x, 0x02000000u);         /* Y0 Y0 Y0 Y1 */
+                    w.b = perm(v.y, v.x, 0x04040202u);       /* Y1 Y1 Y2 Y2 */
+                    w.c = perm(0, v.y, 0x02020200u);         /* Y2 Y3 Y3 Y3 */
+                    *reinterpret_cast<Rgb4 *>(o) = w;
+                }
+            } else {
+                const uint32_t yy[4] = {v.x & 0xFFu, (v.x >> 16) & 0xFFu, v.y & 0xFFu, (v.y >> 16) & 0xFFu};
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) {
+                    if (gx + k < im.X) store_px(o, k, yy[k] * 0x010101u, g.rgba);
+                }
+            }
         }
         return;
     }
     {
-        const uint32_t ch = im.hmax / im.comp[1].hsf, cv = im.vmax / im.comp[1].vsf;
+        const uint32_t ch = im.hmax / im.comp[1].hsf, cv2 = im.vmax / im.comp[1].vsf;
         const bool same = im.comp[1].hsf == 1 && im.comp[1].vsf == 1 && im.comp[2].hsf == 1 && im.comp[2].vsf == 1 &&
                           im.comp[0].hsf == im.hmax && im.comp[0].vsf == im.vmax;
-        if (same && ch != 3 && cv <= 2) {
-#define MJ_FAST(SH, SV)                                                                                          \
-    colour_fast<SH, SV>(s_smp, s_tcb, s_tcr, bpm, sb0, sb1, sb2, tile_w, tile_h, px0, py0, im.X, im.Y, im.pitch, rgb, rgba)
-            if (cv == 1) {
-                if (ch == 1) MJ_FAST(0, 0);
-                else if (ch == 2) MJ_FAST(1, 0);
-                else MJ_FAST(2, 0);
+        if (same && ch != 3 && cv2 <= 2) {
+            if (cv2 == 1) {
+                if (ch == 1) colour_fast<0, 0>(s_smp, s_tab, g, rgb);
+                else if (ch == 2) colour_fast<1, 0>(s_smp, s_tab, g, rgb);
+                else colour_fast<2, 0>(s_smp, s_tab, g, rgb);
             } else {
-                if (ch == 1) MJ_FAST(0, 1);
-                else if (ch == 2) MJ_FAST(1, 1);
-                else MJ_FAST(2, 1);
+                if (ch == 1) colour_fast<0, 1>(s_smp, s_tab, g, rgb);
+                else if (ch == 2) colour_fast<1, 1>(s_smp, s_tab, g, rgb);
+                else colour_fast<2, 1>(s_smp, s_tab, g, rgb);
             }
-#undef MJ_FAST
             return;
         }
     }
@@ -520,22 +561,20 @@ __global__ __launch_bounds__(TPB, MJ_IDCT_WAVES) void mj_k_idct_colour(MjDeviceB
      * factors divide the maximum here, so that is i / (max_sf / sf_c). */
     const uint32_t qh0 = im.hmax / im.comp[0].hsf, qh1 = im.hmax / im.comp[1].hsf, qh2 = im.hmax / im.comp[2].hsf;
     const uint32_t qv0 = im.vmax / im.comp[0].vsf, qv1 = im.vmax / im.comp[1].vsf, qv2 = im.vmax / im.comp[2].vsf;
-    for (; y < tile_h; y += dy, qx += dq) {
+    for (; y < g.tile_h; y += dy, qx += dq) {
         if (qx >= quads) {
             qx -= quads;
             y++;
-            if (y >= tile_h) break;
+            if (y >= g.tile_h) break;
         }
-        const uint32_t x = qx * 4, gy = py0 + y, gx = px0 + x;
+        const uint32_t x = qx * 4, gy = g.py0 + y, gx = g.px0 + x;
         if (gy >= im.Y || gx >= im.X) continue;
-        uint32_t px[4];
-#pragma unroll
-        for (uint32_t k = 0; k < 4; k++) {
+        uint8_t *o = rgb + (uint64_t) gy * im.pitch + bpp * gx;
+        for (uint32_t k = 0; k < 4 && gx + k < im.X; k++) {
             const uint32_t xx = x + k;
-            px[k] = ycc_to_rgb24(s_smp[smp(sb0, hs0, xx / qh0, y / qv0)], s_tcb[s_smp[smp(sb1, hs1, xx / qh1, y / qv1)]],
-                                 s_tcr[s_smp[smp(sb2, hs2, xx / qh2, y / qv2)]]);
+            const uint32_t Y = smp(sb0, hs0, xx / qh0, y / qv0), cb = smp(sb1, hs1, xx / qh1, y / qv1), cr = smp(sb2, hs2, xx / qh2, y / qv2);
+            store_px(o, k, mj_ycc_to_rgb(Y, cb, cr, s_tab[cb], s_tab[256 + cr]), g.rgba);
         }
-        store_quad(rgb + (uint64_t) gy * im.pitch + bpp * gx, px, gx, im.X, rgba);
     }
 }
 

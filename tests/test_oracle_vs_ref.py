@@ -23,6 +23,26 @@ def test_colour_exhaustive_all_triples(oracle, ref):
             assert np.array_equal(a, b), f"colour differs at Y={y}"
 
 
+def test_kernel_colour_arithmetic_all_triples(ref):
+    """The integer form of the colour transform that the IDCT + colour kernel uses
+    (csrc/mj_colour_core.h: per-chroma offsets for R and B, a 2^-20 fixed-point sum for G, the
+    one wrapping triple patched) equals colour_conversion.c:66-79 as compiled, on all 2^24
+    (Y, Cb, Cr) triples."""
+    import jpeg_decoder_amd as J
+    emu = J.Emu()
+    cb, cr = np.meshgrid(np.arange(256, dtype=np.uint8), np.arange(64, dtype=np.uint8), indexing="ij")
+    cb = cb.ravel()
+    for y in range(256):
+        yv = np.full(cb.size, y, np.uint8)
+        for q in range(4):      # the reference's row width is 16 bits: a quarter of the (Cb, Cr) plane per call
+            crq = (cr.ravel() + 64 * q).astype(np.uint8)
+            assert np.array_equal(ref.ycbcr_row(yv, cb, crq), emu.ycbcr_row(yv, cb, crq)), f"colour differs at Y={y}"
+    # the kernel recognises the one chroma pair whose G can wrap by the sum of its G shares
+    assert emu.lib.mj_emu_wrap_sum_pairs() == 1
+    assert tuple(emu.ycbcr_row([219], [228], [28])[0]) == tuple(ref.ycbcr_row([219], [228], [28])[0]) and \
+        emu.ycbcr_row([219], [228], [28])[0][1] == 0
+
+
 def _random_blocks(rng, n):
     blocks = np.zeros((n, 64), np.int16)
     for i in range(n):

@@ -27,7 +27,8 @@ def _run_static(ctx, files, flags, coefs_t, rgb_t):
     bpp = 4 if flags & binding.MJ_OUT_RGBA else 3
     for i in range(len(files)):
         inf = view.info(i)
-        c = coefs_t[inf.coef_offset * 64:(inf.coef_offset + inf.n_blocks) * 64].cpu().numpy().reshape(-1, 64)
+        # the caller's buffer holds blocks in natural order; compare in zigzag order, as mj_batch_copy_coefs reports them
+        c = coefs_t[inf.coef_offset * 64:(inf.coef_offset + inf.n_blocks) * 64].cpu().numpy().reshape(-1, 64)[:, binding.NATPOS]
         raw = rgb_t[inf.rgb_offset:inf.rgb_offset + inf.rgb_pitch * inf.Y].cpu().numpy().reshape(inf.Y, inf.rgb_pitch)
         got.append((c, raw[:, :bpp * inf.X].reshape(inf.Y, inf.X, bpp), view.status(i)))
     return got
