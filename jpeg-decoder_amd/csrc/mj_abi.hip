@@ -75,7 +75,7 @@ constexpr size_t kStaticMetaBytes = 4u << 20;   /* page-locked mirror of the met
 /* offsets of every device buffer inside its region (all multiples of 256) */
 struct Offsets {
     /* meta */
-    size_t img, sets, tile_img, wg_img, idct_img, idct_first, meta_bytes;
+    size_t img, sets, tile_img, wg_img, idct_img, meta_bytes;
     /* state */
     size_t dyn, tile_cnt, tile_base, ivl_start, ivl_seq, seq_ivl, seq_sub, seq_entry, seq_seen, seq_flag, multi, multi_count,
         stats, state_bytes;
@@ -123,7 +123,8 @@ struct mj_batch {
     std::vector<MjImageDev> img;
     std::vector<mj_image_info> info;
     std::vector<MjHuffSet> sets;
-    std::vector<uint32_t> tile_img, wg_img, idct_img, idct_first;
+    std::vector<uint32_t> tile_img, wg_img;
+    std::vector<MjIdctImg> idct_img;
     Offsets o{};
     uint64_t raw_bytes = 0;
     const uint8_t *span_src = nullptr;   /* non-null: the images' bytes lie close together in page-locked memory and leave as one copy from here */
@@ -312,6 +313,37 @@ bool find_span(const std::vector<MjPrepared> &prep, const uint8_t **src, uint64_
     return true;
 }
 
+/* the IDCT + colour kernel's record of an image whose placement (coef_off, rgb_off, pitch,
+ * idct_tiles_x, idct_tile_mcus) is final */
+MjIdctImg idct_record(const MjImageDev &im, uint32_t first_tile) {
+    MjIdctImg r{};
+    r.coef_off = im.coef_off;
+    r.rgb_off = im.rgb_off;
+    r.X = im.X;
+    r.Y = im.Y;
+    r.pitch = im.pitch;
+    r.mcus_x = im.mcus_x;
+    r.geo = im.bpm | (im.idct_tile_mcus << 8) | (im.hmax << 16) | (im.vmax << 24);
+    uint32_t first[3] = {0, 0, 0};
+    for (uint32_t i = im.bpm; i-- > 0;) {
+        r.slot_comp |= (uint32_t) (im.blk_comp[i] & 3u) << (2 * i);
+        if (im.blk_comp[i] < 3) first[im.blk_comp[i]] = i;
+    }
+    for (uint32_t c = 0; c < im.ncs && c < 3; c++) r.sf |= (im.comp[c].hsf | (im.comp[c].vsf << 4)) << (8 * c);
+    uint32_t cl = MJ_CL_GENERIC;
+    if (im.ncs == 1) {
+        cl = MJ_CL_GREY;
+    } else if (im.ncs == 3 && im.comp[1].hsf == 1 && im.comp[1].vsf == 1 && im.comp[2].hsf == 1 && im.comp[2].vsf == 1 &&
+               im.comp[0].hsf == im.hmax && im.comp[0].vsf == im.vmax && im.hmax != 3 && im.vmax <= 2) {
+        cl = MJ_CL_FAST + (im.hmax == 4 ? 2u : im.hmax - 1u) + 3u * (im.vmax - 1u);
+    }
+    r.cls = cl | (first[0] << 8) | (first[1] << 16) | (first[2] << 24);
+    r.first_tile = first_tile;
+    r.n_tiles = im.mcus_y * im.idct_tiles_x;
+    r.tiles_x = im.idct_tiles_x;
+    return r;
+}
+
 int layout(mj_batch *b, const MjPrep &pp, uint32_t flags, bool may_span) {
     const std::vector<MjPrepared> &prep = pp.img;
     const int n = (int) prep.size();
@@ -324,8 +356,7 @@ int layout(mj_batch *b, const MjPrep &pp, uint32_t flags, bool may_span) {
     b->sets = pp.sets;
     b->tile_img.clear();
     b->wg_img.clear();
-    b->idct_img.clear();
-    b->idct_first.assign(n, 0);
+    b->idct_img.assign((size_t) n, MjIdctImg{});
 
     uint64_t raw_total = 0, cmp_total = 0, coef_blocks = 0, rgb_total = 0, plane_total = 0;
     uint64_t n_tiles = 0, n_ivl = 0, n_seq = 0, n_rec = 0, n_wg = 0, n_multi = 0, n_idct = 0;
@@ -373,12 +404,13 @@ int layout(mj_batch *b, const MjPrep &pp, uint32_t flags, bool may_span) {
         uint64_t mc = im.raw_len * 8 / seq_bits;
         im.multi_cap = (uint32_t) (mc < im.n_ivl ? mc : im.n_ivl);
         n_multi += im.multi_cap;
-        const uint32_t iw = im.mcus_y * mj_idct_tiles_x(im.mcus_x, im.bpm, im.hmax);
-        b->idct_first[i] = (uint32_t) n_idct;
+        im.idct_tile_mcus = mj_idct_tile_mcus(im.bpm);
+        im.idct_tiles_x = (im.mcus_x + im.idct_tile_mcus - 1) / im.idct_tile_mcus;
+        const uint32_t iw = im.mcus_y * im.idct_tiles_x;
+        b->idct_img[i] = idct_record(im, (uint32_t) n_idct);
         n_idct += iw;
         b->tile_img.insert(b->tile_img.end(), im.n_tiles, (uint32_t) i);
         b->wg_img.insert(b->wg_img.end(), wgs, (uint32_t) i);
-        b->idct_img.insert(b->idct_img.end(), iw, (uint32_t) i);
         if (n_tiles >= (1ull << 31) || n_seq >= (1ull << 31) || n_rec >= (1ull << 31) || n_idct >= (1ull << 31) || n_ivl >= (1ull << 31)) {
             return set_err("batch too large");
         }
@@ -412,7 +444,7 @@ int layout(mj_batch *b, const MjPrep &pp, uint32_t flags, bool may_span) {
     d.n_tiles = (uint32_t) n_tiles;
     d.n_entropy_wg = (uint32_t) n_wg;
     d.n_multi_cap = (uint32_t) n_multi;
-    d.n_idct_wg = (uint32_t) n_idct;
+    d.n_idct_tiles = (uint32_t) n_idct;
     d.want_planes = (flags & MJ_WANT_PLANES) ? 1u : 0u;
     d.rgba = (flags & MJ_OUT_RGBA) ? 1u : 0u;
 #if defined(MJ_EXPERIMENT)
@@ -437,8 +469,7 @@ int layout(mj_batch *b, const MjPrep &pp, uint32_t flags, bool may_span) {
     o.sets = m.take(b->sets.size() * sizeof(MjHuffSet));
     o.tile_img = m.take(n_tiles * 4);
     o.wg_img = m.take(n_wg * 4);
-    o.idct_img = m.take(n_idct * 4);
-    o.idct_first = m.take((uint64_t) n * 4);
+    o.idct_img = m.take((uint64_t) n * sizeof(MjIdctImg));
     o.meta_bytes = m.off;
     o.dyn = st.take((uint64_t) n * sizeof(MjImageDyn));
     o.tile_cnt = st.take(n_tiles * sizeof(MjTileCnt));
@@ -473,8 +504,7 @@ void bind(mj_batch *b, uint8_t *meta, uint8_t *state, uint8_t *work, uint8_t *co
     d.sets = reinterpret_cast<const MjHuffSet *>(meta + o.sets);
     d.tile_img = reinterpret_cast<const uint32_t *>(meta + o.tile_img);
     d.wg_img = reinterpret_cast<const uint32_t *>(meta + o.wg_img);
-    d.idct_wg_img = reinterpret_cast<const uint32_t *>(meta + o.idct_img);
-    d.idct_wg_first = reinterpret_cast<const uint32_t *>(meta + o.idct_first);
+    d.idct_img = reinterpret_cast<const MjIdctImg *>(meta + o.idct_img);
     d.dyn = reinterpret_cast<MjImageDyn *>(state + o.dyn);
     d.tile_cnt = reinterpret_cast<MjTileCnt *>(state + o.tile_cnt);
     d.tile_base = reinterpret_cast<MjTileBase *>(state + o.tile_base);
@@ -562,8 +592,7 @@ int upload(mj_batch *b, const std::vector<MjPrepared> &prep, uint8_t *meta, uint
     memcpy(mh + o.sets, b->sets.data(), b->sets.size() * sizeof(MjHuffSet));
     memcpy(mh + o.tile_img, b->tile_img.data(), b->tile_img.size() * 4);
     memcpy(mh + o.wg_img, b->wg_img.data(), b->wg_img.size() * 4);
-    memcpy(mh + o.idct_img, b->idct_img.data(), b->idct_img.size() * 4);
-    memcpy(mh + o.idct_first, b->idct_first.data(), n * 4);
+    memcpy(mh + o.idct_img, b->idct_img.data(), n * sizeof(MjIdctImg));
     HIP_TRY(hipMemcpyAsync(meta, mh, o.meta_bytes, hipMemcpyHostToDevice, s));
     uint8_t *raw = const_cast<uint8_t *>(b->d.raw);
     if (b->span_src) {

@@ -136,8 +136,32 @@ typedef struct {
     uint32_t multi_cap;  /* upper bound on intervals longer than one sequence */
     uint32_t lane_subs;  /* consecutive subsequences one lane decodes (1..MJ_MAX_LANE_SUBS) */
     uint32_t rec_off;    /* first subsequence record of the image; sequence q starts at rec_off + q * 64 * lane_subs */
+    uint32_t idct_tiles_x;    /* tiles of the IDCT + colour kernel per MCU row */
+    uint32_t idct_tile_mcus;  /* MCUs per tile (the last tile of a row may hold fewer) */
     uint32_t pad_;
 } MjImageDev;
+
+/* What the IDCT + colour kernel needs to know about an image, in one 64-byte record that a
+ * wavefront reads with a single scalar load. */
+typedef struct {
+    uint64_t coef_off;   /* first 8x8 block in the coefficient buffer */
+    uint64_t rgb_off;    /* first byte in the RGB buffer */
+    uint32_t X, Y;
+    uint32_t pitch;      /* RGB row pitch in bytes */
+    uint32_t mcus_x;
+    uint32_t geo;        /* bpm | MCUs per tile << 8 | hmax << 16 | vmax << 24 */
+    uint32_t slot_comp;  /* frame component of block slot i of the MCU in bits 2i, 2i + 1 */
+    uint32_t cls;        /* colour layout (MJ_CL_*) | first block slot of component 0 << 8 | of 1 << 16 | of 2 << 24 */
+    uint32_t sf;         /* hsf | vsf << 4 of component c in bits 8c .. 8c + 7 */
+    uint32_t first_tile; /* index of the image's first tile in the batch */
+    uint32_t n_tiles;    /* tiles per MCU row x MCU rows */
+    uint32_t tiles_x;    /* tiles per MCU row */
+    uint32_t pad_;
+} MjIdctImg;
+/* colour layouts: one component; three with luma at full resolution and both chroma
+ * components subsampled by 2^SH x 2^SV with one block per MCU (MJ_CL_FAST + SH + 3 * SV);
+ * anything else */
+enum { MJ_CL_GREY = 0, MJ_CL_FAST = 1, MJ_CL_GENERIC = 7 };
 
 /* Values the scan kernels compute per image (device-written). */
 typedef struct {

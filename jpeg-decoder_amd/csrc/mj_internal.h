@@ -34,7 +34,7 @@ struct MjDeviceBatch {
     uint32_t n_tiles;        /* scan tiles over the whole batch */
     uint32_t n_entropy_wg;   /* entropy workgroups (MJ_WG_SEQS sequences each) */
     uint32_t n_multi_cap;    /* capacity of the multi-sequence interval list */
-    uint32_t n_idct_wg;      /* dequant+IDCT+colour workgroups */
+    uint32_t n_idct_tiles;   /* tiles of the dequant+IDCT+colour kernel (one wavefront works on a tile) */
     uint32_t want_planes;
     uint32_t rgba;           /* 1: four bytes per pixel (R, G, B, 255) */
     uint32_t max_ntab;       /* largest Huffman table set in the batch (sizes the kernels' LDS) */
@@ -60,8 +60,7 @@ struct MjDeviceBatch {
     uint2 *multi;            /* (image, interval) of intervals longer than one sequence */
     uint32_t *multi_count;
     const uint32_t *wg_img;  /* [n_entropy_wg] image of each entropy workgroup */
-    const uint32_t *idct_wg_img; /* [n_idct_wg] image of each IDCT workgroup */
-    const uint32_t *idct_wg_first; /* [n_img] first IDCT workgroup of each image */
+    const MjIdctImg *idct_img; /* [n_img] what the IDCT + colour kernel reads per image */
     int16_t *coefs;
     uint8_t *planes;
     uint8_t *rgb;
@@ -85,34 +84,14 @@ hipError_t mj_launch_entropy_write(const MjDeviceBatch &b, hipStream_t s);
 hipError_t mj_launch_entropy_serial(const MjDeviceBatch &b, hipStream_t s);
 hipError_t mj_launch_idct_colour(const MjDeviceBatch &b, hipStream_t s);
 
-/* tile geometry of the IDCT kernel for one image (host + device) */
+/* Tile geometry of the IDCT kernel (host + device).  A tile is a run of consecutive MCUs
+ * of one MCU row that one wavefront takes from coefficients to RGB: at most
+ * MJ_IDCT_TILE_BLOCKS blocks (eight lanes work on a block: three passes of eight blocks). */
 #define MJ_IDCT_THREADS 512
-#define MJ_IDCT_MAX_BLOCKS 256
-/* The kernel keeps the samples of a tile in LDS, sixteen bits per sample: 128 bytes per
- * block, and 16 bytes between MCUs so that the row reads of neighbouring threads fall on
- * different banks.  Three workgroups share the 160 KiB of a compute unit. */
-#define MJ_IDCT_SAMPLE_BYTES 34304
-static inline __host__ __device__ uint32_t mj_idct_mcu_bytes(uint32_t bpm) {
-    return bpm * 128u + 16u;
-}
-/* MCUs per tile: at most MJ_IDCT_MAX_BLOCKS blocks (eight lanes work on a block, 64 blocks per pass). */
-static inline __host__ __device__ uint32_t mj_idct_tile_cap(uint32_t bpm, uint32_t hmax) {
-    /* the colour stage numbers groups of four pixels of a tile row by thread: at most
-     * MJ_IDCT_THREADS of them, i.e. a tile is at most 4 * MJ_IDCT_THREADS pixels wide */
-    uint32_t tmax = MJ_IDCT_MAX_BLOCKS / bpm;
-    const uint32_t wmax = (4u * MJ_IDCT_THREADS) / (8u * (hmax ? hmax : 1u));
-    const uint32_t smax = MJ_IDCT_SAMPLE_BYTES / mj_idct_mcu_bytes(bpm);
-    if (tmax > wmax) tmax = wmax;
-    if (tmax > smax) tmax = smax;
-    return tmax ? tmax : 1;
-}
-static inline __host__ __device__ uint32_t mj_idct_tiles_x(uint32_t mcus_x, uint32_t bpm, uint32_t hmax) {
-    const uint32_t tmax = mj_idct_tile_cap(bpm, hmax);
-    return (mcus_x + tmax - 1) / tmax;
-}
-static inline __host__ __device__ uint32_t mj_idct_tile_mcus(uint32_t mcus_x, uint32_t bpm, uint32_t hmax) {
-    const uint32_t tx = mj_idct_tiles_x(mcus_x, bpm, hmax);
-    return (mcus_x + tx - 1) / tx;
+#define MJ_IDCT_TILE_BLOCKS 24
+static inline __host__ __device__ uint32_t mj_idct_tile_mcus(uint32_t bpm) {
+    const uint32_t t = MJ_IDCT_TILE_BLOCKS / (bpm ? bpm : 1u);
+    return t ? t : 1u;
 }
 
 #endif

@@ -7,22 +7,26 @@
  * (dct.c:158-204, :296-341), write_mcu / write_data_unit (decode.c:436-533) and
  * ycbcr_rgb / y_rgb (colour_conversion.c:5-83).
  *
- * Work decomposition: one workgroup per *tile* of T consecutive MCUs of one MCU
- * row.  In scan order those MCUs' blocks are contiguous in the coefficient buffer
- * (luma and chroma of the same pixels sit next to each other), and the entropy stage
- * leaves every block in natural order, so:
- *   1. eight lanes share one 8x8 block, 64 blocks per pass: lane r loads row r (16 bytes;
- *      the eight lanes of a block read one 128-byte line, all loads of a thread are
- *      issued before the first is used), dequantises it (int16 wrap), runs the row
- *      butterfly, the eight lanes transpose through LDS, lane x runs the column
- *      butterfly, they transpose back, and lane r level-shifts, clamps, truncates and
- *      stores row r of the samples to the tile's sample buffer in LDS, sixteen bits per
- *      sample.  A lane holds eight values, not sixty-four: the kernel runs at six
- *      wavefronts per SIMD, which is what keeps HBM busy while other wavefronts are in
- *      the butterflies;
- *   2. the workgroup walks the tile in patches of 8 x 2^v pixels: nearest-neighbour
- *      chroma lookup, colour transform in packed 16-bit integers, saturating pack, and
- *      24-byte coalesced stores of RGB24.
+ * Work decomposition: one *wavefront* per tile of consecutive MCUs of one MCU row, at
+ * most 24 blocks (4 MCUs of 4:2:0, 64 x 16 pixels).  In scan order those MCUs' blocks are
+ * contiguous in the coefficient buffer (luma and chroma of the same pixels sit next to
+ * each other), and the entropy stage leaves every block in natural order, so:
+ *   1. eight lanes share one 8x8 block, 8 blocks per pass: lane r loads row r (16 bytes;
+ *      the eight lanes of a block read one 128-byte line), dequantises it (int16 wrap),
+ *      runs the row butterfly, the eight lanes transpose through LDS, lane x runs the
+ *      column butterfly, they transpose back, and lane r level-shifts, clamps, truncates
+ *      and stores row r of the samples to the wavefront's sample buffer in LDS, sixteen
+ *      bits per sample;
+ *   2. the wavefront walks its tile in patches of 8 x 2^v pixels, one per lane:
+ *      nearest-neighbour chroma lookup, colour transform in packed 16-bit integers,
+ *      saturating pack, and 24-byte stores of RGB24.
+ * Wavefronts are persistent and independent of each other -- no workgroup barrier after
+ * the start -- so at any time some are in the arithmetic of step 1 while others wait
+ * for their stores of step 2, and the load on HBM is even.  Every wavefront takes tiles
+ * w, w + W, w + 2W, ... (W wavefronts on the chip); the four wavefronts next to each other
+ * write neighbouring 192-byte pieces of the same RGB rows.  The coefficient rows of a
+ * wavefront's next tile are requested as soon as the butterflies have consumed the
+ * current ones and arrive during the colour stage.
  *
  * The IDCT arithmetic follows the reference's rounding points exactly: float storage,
  * double constants, no fused multiply-add (the file is compiled with
@@ -37,12 +41,15 @@
 namespace {
 
 constexpr int TPB = MJ_IDCT_THREADS;
-constexpr int GROUPS = TPB / 8;                /* blocks per pass */
-constexpr int MAXB = MJ_IDCT_MAX_BLOCKS;
-constexpr int PASSES = (MAXB + GROUPS - 1) / GROUPS;
+constexpr int WAVES = TPB / 64;                /* independent wavefronts per workgroup */
+constexpr int MAXB = MJ_IDCT_TILE_BLOCKS;      /* blocks per tile */
+constexpr int PASSES = (MAXB + 7) / 8;         /* eight blocks per pass */
 constexpr int TR_GROUP = 72;                   /* floats per 8x8 transpose buffer: 64 + 8, conflict-free strided access */
-constexpr int TR_BYTES = GROUPS * TR_GROUP * 4;
-constexpr int SMP_BYTES = MJ_IDCT_SAMPLE_BYTES;
+constexpr int TR_BYTES = 8 * TR_GROUP * 4;     /* per wavefront */
+constexpr int SMP_BYTES = MAXB * 128 + MAXB * 16;   /* per wavefront: 128 bytes per block, 16 between MCUs */
+constexpr int QT_BYTES = MJ_MAX_COMP * 64 * 2; /* per wavefront: the quantiser tables of its image */
+constexpr int WAVE_BYTES = SMP_BYTES + TR_BYTES + QT_BYTES;
+static_assert(3 * (WAVES * WAVE_BYTES + 512 * 8) <= 160 * 1024, "three workgroups per compute unit");
 constexpr uint32_t BLK_BYTES = 128;            /* a block of samples in LDS: 8 rows of 8 x 16 bits */
 
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -188,11 +195,12 @@ __device__ __forceinline__ uint32_t add_pair(uint32_t y, uint32_t o) {
 struct __attribute__((aligned(4))) Rgb4 {
     uint32_t a, b, c;
 };
+template <bool RGBA>
 __device__ __forceinline__ void store4(uint8_t *o, uint32_t r01, uint32_t g01, uint32_t b01, uint32_t r23, uint32_t g23,
-                                       uint32_t b23, bool rgba) {
+                                       uint32_t b23) {
     const uint32_t gb01 = perm(b01, g01, 0x05040100u);   /* G0 G1 B0 B1 */
     const uint32_t rg23 = perm(g23, r23, 0x05040100u);   /* R2 R3 G2 G3 */
-    if (rgba) {
+    if (RGBA) {
         *reinterpret_cast<uint4 *>(o) = make_uint4(perm(gb01, r01, 0x0d060400u), perm(gb01, r01, 0x0d070501u),
                                                    perm(rg23, b23, 0x0d000604u), perm(rg23, b23, 0x0d010705u));
     } else {
@@ -218,6 +226,21 @@ __device__ __forceinline__ void store_px(uint8_t *o, uint32_t k, uint32_t px, bo
 #ifndef MJ_IDCT_WAVES
 #define MJ_IDCT_WAVES 6
 #endif
+#define MJ_IDCT_WG_PER_CU 3
+
+/* Timing experiments only (-DMJ_IDCT_TRACE): the first thread of every workgroup adds the
+ * shader-clock time it spends in each phase of a tile to the batch's statistics words,
+ * over what the entropy kernels left there. */
+#if defined(MJ_IDCT_TRACE)
+#define MJ_STAMP(i) \
+    do { \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        acc_[i] += now_ - stamp_; \
+        stamp_ = now_; \
+    } while (0)
+#else
+#define MJ_STAMP(i) do { } while (0)
+#endif
 
 /* Where the samples of the tile live after the butterflies: block `blk` of MCU `mcu` of
  * the tile (blk counted over the whole tile) keeps its 8x8 samples row-major, sixteen
@@ -232,6 +255,7 @@ struct TileGeo {
     uint32_t px0, py0;                 /* the tile's first pixel in the image */
     uint32_t X, Y, pitch;
     bool rgba;
+    bool fold;                         /* timing experiments only */
 };
 
 /*
@@ -243,16 +267,23 @@ struct TileGeo {
  * channel: one packed 16-bit add of the two luma samples and the channel's offset, one
  * saturating pack; byte permutes put four pixels' channels in RGB order.
  */
-template <int SH, int SV>
-__device__ __forceinline__ void colour_fast(const uint8_t *s_smp, const MjChromaTerm *s_tab, const TileGeo &g, uint8_t *rgb) {
+template <int SH, int SV, bool RGBA>
+__device__ __forceinline__ void colour_fast(const uint8_t *s_smp, const MjChromaTerm *s_tab, const TileGeo &g, uint8_t *rgb, uint32_t lane) {
     constexpr int NC = 8 >> SH, ROWS = 1 << SV;          /* chroma samples per patch row; pixel rows per patch */
     constexpr int NCW = (NC + 1) / 2;                    /* words that hold them */
-    const uint32_t bpp = g.rgba ? 4u : 3u;
+    constexpr uint32_t bpp = RGBA ? 4u : 3u;
     const uint32_t cols = g.tile_w / 8, prow_n = g.tile_h >> SV;
-    const uint32_t dy = TPB / cols, dq = TPB - dy * cols;
+    const uint32_t dy = 64 / cols, dq = 64 - dy * cols;
+#if defined(MJ_EXPERIMENT)
+    /* timing experiment: every tile's rows land in the same 64 KiB */
+    uint8_t *rgb_tile = g.fold ? rgb + ((threadIdx.x >> 6) << 16) : rgb + (uint64_t) g.py0 * g.pitch;
+    const uint32_t fold_mask = g.fold ? 0xFFFFu : 0xFFFFFFFFu;
+#else
     uint8_t *rgb_tile = rgb + (uint64_t) g.py0 * g.pitch;
-    uint32_t pr = threadIdx.x / cols;
-    uint32_t qx = threadIdx.x - pr * cols;
+    constexpr uint32_t fold_mask = 0xFFFFFFFFu;
+#endif
+    uint32_t pr = lane / cols;
+    uint32_t qx = lane - pr * cols;
     for (; pr < prow_n; pr += dy, qx += dq) {
         if (qx >= cols) {
             qx -= cols;
@@ -289,224 +320,75 @@ __device__ __forceinline__ void colour_fast(const uint8_t *s_smp, const MjChroma
             const uint32_t lblk = mblk + g.s0 + ((ly >> 3) << SH) + lcol;
             yw[r] = *reinterpret_cast<const uint4 *>(s_smp + sample_off(mcu, lblk, 0, ly));
         }
-        /* per chroma sample: the three channel offsets */
-        uint32_t oR[NC], oG[NC], oB[NC];
-        bool wraps = false;
-#pragma unroll
-        for (int i = 0; i < NC; i++) {
-            const uint32_t cb = (cbw[i >> 1] >> (16 * (i & 1))) & 0xFFFFu, cr = (crw[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
-            const MjChromaTerm tb = s_tab[cb], tr = s_tab[256 + cr];
-            const int32_t gs = tb.g + tr.g;
-            wraps |= (gs == WRAP_GSUM);
-            oR[i] = tr.o;
-            oG[i] = (uint32_t) (gs >> MJ_G_FRAC_BITS);
-            oB[i] = tb.o;
-        }
         const bool whole = (gx + 8 <= g.X) && (gy + ROWS <= g.Y);
-        if (whole && !wraps) {
+        /* four pixels of every row at a time: the chroma samples they share, then the rows */
 #pragma unroll
-            for (int r = 0; r < ROWS; r++) {
-                const uint32_t yp[4] = {yw[r].x, yw[r].y, yw[r].z, yw[r].w};   /* pixel pairs of the row */
-                uint32_t cr8[4], cg8[4], cb8[4];
+        for (int h = 0; h < 2; h++) {
+            constexpr int NCH = (NC >= 2) ? NC / 2 : 1;      /* chroma samples per half row */
+            uint32_t oR[NCH], oG[NCH], oB[NCH];
+            bool wraps = false;
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    if (SH == 0) {
-                        cr8[j] = sat_pk(add_pair(yp[j], perm(oR[(2 * j + 1) % NC], oR[(2 * j) % NC], 0x05040100u)));
-                        cg8[j] = sat_pk(add_pair(yp[j], perm(oG[(2 * j + 1) % NC], oG[(2 * j) % NC], 0x05040100u)));
-                        cb8[j] = sat_pk(add_pair(yp[j], perm(oB[(2 * j + 1) % NC], oB[(2 * j) % NC], 0x05040100u)));
-                    } else {
-                        const int i = (2 * j) >> SH;
-                        cr8[j] = sat_pk(add_pair_shared(yp[j], oR[i]));
-                        cg8[j] = sat_pk(add_pair_shared(yp[j], oG[i]));
-                        cb8[j] = sat_pk(add_pair_shared(yp[j], oB[i]));
-                    }
-                }
-                /* rows of one tile are at most a few megabytes apart: 32-bit offsets from the
-                 * tile's first row */
-                uint8_t *o = rgb_tile + (__umul24(y + r, g.pitch) + bpp * gx);
-                store4(o, cr8[0], cg8[0], cb8[0], cr8[1], cg8[1], cb8[1], g.rgba);
-                store4(o + 4 * bpp, cr8[2], cg8[2], cb8[2], cr8[3], cg8[3], cb8[3], g.rgba);
+            for (int i = 0; i < NCH; i++) {
+                const int ci = (NC >= 2) ? h * NCH + i : 0;
+                const uint32_t cb = (cbw[ci >> 1] >> (16 * (ci & 1))) & 0xFFFFu, cr = (crw[ci >> 1] >> (16 * (ci & 1))) & 0xFFFFu;
+                const MjChromaTerm tb = s_tab[cb], tr = s_tab[256 + cr];
+                const int32_t gs = tb.g + tr.g;
+                wraps |= (gs == WRAP_GSUM);
+                oR[i] = tr.o;
+                oG[i] = (uint32_t) (gs >> MJ_G_FRAC_BITS);
+                oB[i] = tb.o;
             }
-        } else {
-            /* patches cut by the image edge, and the one chroma pair for which a luma value
-             * exists that wraps G (colour_conversion.c:78): pixel by pixel */
-            for (uint32_t r = 0; r < (uint32_t) ROWS && gy + r < g.Y; r++) {
-                const uint32_t ly = y + r;
-                const uint32_t lblk = mblk + g.s0 + ((ly >> 3) << SH) + lcol;
-                uint8_t *o = rgb_tile + (__umul24(ly, g.pitch) + bpp * gx);
-                for (uint32_t k = 0; k < 8 && gx + k < g.X; k++) {
-                    const uint32_t Y = *reinterpret_cast<const uint16_t *>(s_smp + sample_off(mcu, lblk, k, ly));
-                    const uint32_t cb = *reinterpret_cast<const uint16_t *>(cbp + 2 * (k >> SH));
-                    const uint32_t cr = *reinterpret_cast<const uint16_t *>(crp + 2 * (k >> SH));
-                    store_px(o + 4 * bpp * (k >> 2), k & 3u, mj_ycc_to_rgb(Y, cb, cr, s_tab[cb], s_tab[256 + cr]), g.rgba);
+            if (whole && !wraps) {
+#pragma unroll
+                for (int r = 0; r < ROWS; r++) {
+                    const uint32_t yp[2] = {h ? yw[r].z : yw[r].x, h ? yw[r].w : yw[r].y};   /* the two pixel pairs */
+                    uint32_t cr8[2], cg8[2], cb8[2];
+#pragma unroll
+                    for (int j = 0; j < 2; j++) {
+                        if (SH == 0) {
+                            cr8[j] = sat_pk(add_pair(yp[j], perm(oR[(2 * j + 1) % NCH], oR[(2 * j) % NCH], 0x05040100u)));
+                            cg8[j] = sat_pk(add_pair(yp[j], perm(oG[(2 * j + 1) % NCH], oG[(2 * j) % NCH], 0x05040100u)));
+                            cb8[j] = sat_pk(add_pair(yp[j], perm(oB[(2 * j + 1) % NCH], oB[(2 * j) % NCH], 0x05040100u)));
+                        } else {
+                            const int i = (SH == 1) ? j : 0;
+                            cr8[j] = sat_pk(add_pair_shared(yp[j], oR[i]));
+                            cg8[j] = sat_pk(add_pair_shared(yp[j], oG[i]));
+                            cb8[j] = sat_pk(add_pair_shared(yp[j], oB[i]));
+                        }
+                    }
+                    /* rows of one tile are at most a few megabytes apart: 32-bit offsets from the
+                     * tile's first row */
+                    store4<RGBA>(rgb_tile + ((__umul24(y + r, g.pitch) + bpp * (gx + 4 * h)) & fold_mask), cr8[0], cg8[0], cb8[0], cr8[1], cg8[1], cb8[1]);
+                }
+            } else {
+                /* pixels cut off by the image edge, and the one chroma pair for which a luma value
+                 * exists that wraps G (colour_conversion.c:78): pixel by pixel */
+                for (uint32_t r = 0; r < (uint32_t) ROWS && gy + r < g.Y; r++) {
+                    const uint32_t ly = y + r;
+                    const uint32_t lblk = mblk + g.s0 + ((ly >> 3) << SH) + lcol;
+                    uint8_t *o = rgb_tile + (__umul24(ly, g.pitch) + bpp * (gx + 4 * h));
+                    for (uint32_t k = 0; k < 4 && gx + 4 * h + k < g.X; k++) {
+                        const uint32_t kk = 4 * h + k;
+                        const uint32_t Y = *reinterpret_cast<const uint16_t *>(s_smp + sample_off(mcu, lblk, kk, ly));
+                        const uint32_t cb = *reinterpret_cast<const uint16_t *>(cbp + 2 * (kk >> SH));
+                        const uint32_t cr = *reinterpret_cast<const uint16_t *>(crp + 2 * (kk >> SH));
+                        store_px(o, k, mj_ycc_to_rgb(Y, cb, cr, s_tab[cb], s_tab[256 + cr]), RGBA);
+                    }
                 }
             }
         }
     }
 }
 
-__global__ __launch_bounds__(TPB, MJ_IDCT_WAVES) void mj_k_idct_colour(MjDeviceBatch b) {
-    /* LDS: the tile's samples; the transpose buffers of the butterflies, which later hold
-     * the two chroma tables; the quantiser table of every block slot of the MCU */
-    __shared__ __align__(16) uint8_t s_smp[SMP_BYTES];
-    __shared__ __align__(16) uint8_t s_tr[TR_BYTES];
-    __shared__ __align__(16) uint16_t s_qt[MJ_MAX_BPM + 2][64];
-    MjChromaTerm *s_tab = reinterpret_cast<MjChromaTerm *>(s_tr);
-    static_assert(sizeof(MjChromaTable) <= TR_BYTES, "the chroma tables reuse the transpose buffers");
-    static_assert(sizeof(MjChromaTable) == TPB * sizeof(MjChromaTerm), "one table row per thread");
-
-    const uint32_t ii = b.idct_wg_img[blockIdx.x];
-    const MjImageDev &im = b.img[ii];
-    const uint32_t bpm = im.bpm;
-    const uint32_t tiles_x = mj_idct_tiles_x(im.mcus_x, bpm, im.hmax);
-    const uint32_t T = mj_idct_tile_mcus(im.mcus_x, bpm, im.hmax);
-    const uint32_t wg = blockIdx.x - b.idct_wg_first[ii];
-    const uint32_t mrow = wg / tiles_x;
-    const uint32_t m0 = (wg % tiles_x) * T;
-    const uint32_t nm = min(T, im.mcus_x - m0);     /* MCUs in this tile */
-    const uint32_t nblk = nm * bpm;
-
-    /* ---- 1. eight lanes per block, 64 blocks per pass ---------------------- */
-    const uint32_t r = threadIdx.x & 7u;                 /* the lane's row, then column, then row again */
-    const uint32_t grp = threadIdx.x >> 3;               /* block within the pass */
-    /* row r of every block this lane works on: the tile is one contiguous run of 16-byte rows */
-    const u4 *src = reinterpret_cast<const u4 *>(b.coefs + (im.coef_off + ((uint64_t) mrow * im.mcus_x + m0) * bpm) * 64);
-    u4 cv[PASSES];
-#pragma unroll
-    for (int p = 0; p < PASSES; p++) {
-        cv[p] = (u4){0, 0, 0, 0};
-        if (p * GROUPS + grp < nblk) cv[p] = __builtin_nontemporal_load(src + p * TPB + threadIdx.x);
-    }
-    for (uint32_t i = threadIdx.x; i < bpm * 64; i += TPB) {
-        s_qt[i >> 6][i & 63] = im.qt[im.blk_comp[i >> 6]][i & 63];
-    }
-    __syncthreads();
-
-    if (!(MJ_DBG(b) & 16u)) {
-        float *tr = reinterpret_cast<float *>(s_tr) + grp * TR_GROUP;
-        /* the reference scales the first row and the first column by 1/sqrt(2) before the
-         * butterflies (dct.c:164-167), the corner twice: lane 0 scales its whole row, the
-         * others multiply by one, which changes nothing */
-        constexpr SplitConst RS = split_const(0.707106781);
-        const SplitConst row_scale = {(r == 0) ? RS.hi : 1.0f, (r == 0) ? RS.lo : 0.0f};
-        const float rcp_bpm = 1.0f / (float) bpm;
-        /* where element j of a row sits after the row butterfly: 0 7 1 6 2 5 3 4 hold positions 0..7 */
-        const uint32_t tpos = (r < 4) ? 2 * r : 15 - 2 * r;
-#pragma unroll
-        for (int p = 0; p < PASSES; p++) {
-            const uint32_t blk = p * GROUPS + grp;
-            if (blk >= nblk) continue;                       /* whole groups of eight lanes drop out together */
-            /* blk + 0.5 over bpm is at least 0.05 away from an integer: the rounding of the
-             * reciprocal and of the product cannot reach one */
-            const uint32_t mcu = (uint32_t) (((float) blk + 0.5f) * rcp_bpm);
-            const uint32_t slot = blk - mcu * bpm;
-            float c[8];
-            {
-                /* int16 wrap of the product (quant_table.c:137): the low halves of the 16-bit products */
-                const us8 q = *reinterpret_cast<const us8 *>(&s_qt[slot][8 * r]);
-                const us8 z = __builtin_bit_cast(us8, cv[p]);
-                const us8 zq = z * q;
-#pragma unroll
-                for (int j = 0; j < 8; j++) c[j] = (float) (int16_t) zq[j];
-            }
-            c[0] = mulc(c[0], RS);                           /* first column */
-            /* first row, two values at a time; c[3] and c[5] together, as the butterfly takes them */
-            const f2 c04 = mulc((f2){c[0], c[4]}, row_scale), c17 = mulc((f2){c[1], c[7]}, row_scale);
-            const f2 c26 = mulc((f2){c[2], c[6]}, row_scale), c35 = mulc((f2){c[3], c[5]}, row_scale);
-            const Idct8Out ro = idct8<false>(c04, c17, c26, c35);
-            /* rows -> columns (the reference transposes, runs rows again, and transposes
-             * back on the store: dct.c:173-193).  The eight lanes of a block sit in one
-             * wavefront, which runs its LDS operations in order.  A row is stored in the
-             * order the butterfly leaves it: 0 7 1 6 2 5 3 4. */
-            *reinterpret_cast<f2 *>(tr + r * 8) = ro.o07;
-            *reinterpret_cast<f2 *>(tr + r * 8 + 2) = ro.o16;
-            *reinterpret_cast<f2 *>(tr + r * 8 + 4) = ro.o25;
-            *reinterpret_cast<f2 *>(tr + r * 8 + 6) = ro.o34;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const float *col = tr + tpos;                    /* element r of every row */
-            const Idct8Out co = idct8<true>((f2){col[0], col[4 * 8]}, (f2){col[1 * 8], col[7 * 8]}, (f2){col[2 * 8], col[6 * 8]},
-                                            (f2){col[3 * 8], col[5 * 8]});
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            tr[0 * 8 + r] = co.o07.x;
-            tr[7 * 8 + r] = co.o07.y;
-            tr[1 * 8 + r] = co.o16.x;
-            tr[6 * 8 + r] = co.o16.y;
-            tr[2 * 8 + r] = co.o25.x;
-            tr[5 * 8 + r] = co.o25.y;
-            tr[3 * 8 + r] = co.o34.x;
-            tr[4 * 8 + r] = co.o34.y;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const float4 lo4 = *reinterpret_cast<const float4 *>(tr + r * 8), hi4 = *reinterpret_cast<const float4 *>(tr + r * 8 + 4);
-            /* row r of the samples */
-            *reinterpret_cast<uint4 *>(s_smp + sample_off(mcu, blk, 0, r)) =
-                make_uint4(finish2(lo4.x, lo4.y), finish2(lo4.z, lo4.w), finish2(hi4.x, hi4.y), finish2(hi4.z, hi4.w));
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
-    __syncthreads();   /* all samples are in place; the transpose buffers are free */
-    s_tab[threadIdx.x] = c_chroma.t[threadIdx.x];
-
-    /* first block slot of each component inside the MCU (scan order: all blocks of a
-     * component are consecutive, decode.c:591-611) */
-    uint32_t sb0 = 0, sb1 = 0, sb2 = 0;
-    for (uint32_t i = bpm; i-- > 0;) {
-        const uint32_t cc = im.blk_comp[i];
-        if (cc == 0) sb0 = i;
-        else if (cc == 1) sb1 = i;
-        else if (cc == 2) sb2 = i;
-    }
-    const uint32_t hs0 = im.comp[0].hsf, hs1 = (im.ncs > 1) ? im.comp[1].hsf : 1u, hs2 = (im.ncs > 2) ? im.comp[2].hsf : 1u;
-    /* sample (x, y) of component c, in tile coordinates of that component */
-    auto smp = [&](uint32_t sb, uint32_t hs, uint32_t x, uint32_t y) -> uint32_t {
-        const uint32_t bx = x >> 3, m = bx / hs, h = bx - m * hs;
-        return *reinterpret_cast<const uint16_t *>(s_smp + sample_off(m, m * bpm + sb + (y >> 3) * hs + h, x, y));
-    };
-    __syncthreads();
-
-    /* ---- optional: the padded component planes (Image.buf, decode.c:517-531) */
-    if (b.want_planes) {
-        for (uint32_t i = threadIdx.x; i < nblk * 8; i += TPB) {
-            const uint32_t blk = i >> 3, row = i & 7u;
-            const uint32_t m = blk / bpm, slot = blk - m * bpm;
-            const uint32_t cc = im.blk_comp[slot];
-            const uint32_t hs = im.comp[cc].hsf, vs = im.comp[cc].vsf;
-            const uint64_t py = (uint64_t) mrow * vs * 8 + im.blk_v[slot] * 8u + row;
-            const uint64_t px = ((uint64_t) (m0 + m) * hs + im.blk_h[slot]) * 8;
-            const uint4 v = *reinterpret_cast<const uint4 *>(s_smp + sample_off(m, blk, 0, row));
-            *reinterpret_cast<uint2 *>(b.planes + im.comp[cc].plane_off + py * im.comp[cc].pw + px) =
-                make_uint2(perm(v.y, v.x, 0x06040200u), perm(v.w, v.z, 0x06040200u));
-        }
-    }
-
-    if (MJ_DBG(b) & 8u) return;
-    /* ---- 2. upsample + colour ---------------------------------------------- */
-    TileGeo g;
-    g.bpm = bpm;
-    g.s0 = sb0;
-    g.s1 = sb1;
-    g.s2 = sb2;
-    g.tile_w = nm * im.hmax * 8;
-    g.tile_h = im.vmax * 8;
-    g.px0 = m0 * im.hmax * 8;
-    g.py0 = mrow * g.tile_h;
-    g.X = im.X;
-    g.Y = im.Y;
-    g.pitch = im.pitch;
-    g.rgba = b.rgba != 0;
-    uint8_t *rgb = b.rgb + im.rgb_off;
-    const uint32_t bpp = g.rgba ? 4u : 3u;
-    /* The generic paths number the tile's quads (4 horizontally adjacent pixels) row-major;
-     * a thread takes quad tid, tid + TPB, ... and tracks (row, quad-in-row) incrementally,
-     * so the loop has no division. */
+/* one component: R = G = B = the sample (y_rgb, colour_conversion.c:5-28), four pixels per lane and step */
+template <bool RGBA>
+__device__ __forceinline__ void colour_grey(const uint8_t *s_smp, const TileGeo &g, uint32_t hs0, uint8_t *rgb, uint32_t lane) {
+    constexpr uint32_t bpp = RGBA ? 4u : 3u;
+    const uint32_t bpm = g.bpm, sb0 = g.s0;
     const uint32_t quads = g.tile_w / 4;
-    const uint32_t dy = TPB / quads, dq = TPB - dy * quads;
-    uint32_t y = threadIdx.x / quads;
-    uint32_t qx = threadIdx.x - y * quads;
-    if (im.ncs == 1) {
+    const uint32_t dy = 64 / quads, dq = 64 - dy * quads;
+    uint32_t y = lane / quads;
+    uint32_t qx = lane - y * quads;
         for (; y < g.tile_h; y += dy, qx += dq) {
             if (qx >= quads) {
                 qx -= quads;
@@ -514,12 +396,12 @@ __global__ __launch_bounds__(TPB, MJ_IDCT_WAVES) void mj_k_idct_colour(MjDeviceB
                 if (y >= g.tile_h) break;
             }
             const uint32_t x = qx * 4, gy = g.py0 + y, gx = g.px0 + x;
-            if (gy >= im.Y || gx >= im.X) continue;
+            if (gy >= g.Y || gx >= g.X) continue;
             const uint32_t bx = x >> 3, m = bx / hs0, h = bx - m * hs0;
             const uint2 v = *reinterpret_cast<const uint2 *>(s_smp + sample_off(m, m * bpm + sb0 + (y >> 3) * hs0 + h, x, y));
-            uint8_t *o = rgb + (uint64_t) gy * im.pitch + bpp * gx;
-            if (gx + 4 <= im.X) {
-                if (g.rgba) {
+            uint8_t *o = rgb + (uint64_t) gy * g.pitch + bpp * gx;
+            if (gx + 4 <= g.X) {
+                if (RGBA) {
                     *reinterpret_cast<uint4 *>(o) = make_uint4(perm(0, v.x, 0x0d000000u), perm(0, v.x, 0x0d020202u),
                                                                perm(0, v.y, 0x0d000000u), perm(0, v.y, 0x0d020202u));
                 } else {
@@ -533,34 +415,58 @@ __global__ __launch_bounds__(TPB, MJ_IDCT_WAVES) void mj_k_idct_colour(MjDeviceB
                 const uint32_t yy[4] = {v.x & 0xFFu, (v.x >> 16) & 0xFFu, v.y & 0xFFu, (v.y >> 16) & 0xFFu};
 #pragma unroll
                 for (uint32_t k = 0; k < 4; k++) {
-                    if (gx + k < im.X) store_px(o, k, yy[k] * 0x010101u, g.rgba);
+                    if (gx + k < g.X) store_px(o, k, yy[k] * 0x010101u, RGBA);
                 }
             }
         }
+}
+
+/* the colour stage of one tile, by the layout of its image */
+__device__ __forceinline__ void colour_tile(const uint8_t *s_smp, const MjChromaTerm *s_tab, const MjIdctImg &im, const TileGeo &g,
+                                            uint8_t *rgb, uint32_t lane) {
+    const uint32_t bpm = g.bpm, sb0 = g.s0, sb1 = g.s1, sb2 = g.s2;
+    const uint32_t cl = im.cls & 0xFFu, hmax = (im.geo >> 16) & 0xFFu, vmax = im.geo >> 24;
+    /* sampling factors of the three components (1 where there is none) */
+    const uint32_t hs0 = max(im.sf & 15u, 1u), hs1 = max((im.sf >> 8) & 15u, 1u), hs2 = max((im.sf >> 16) & 15u, 1u);
+    const uint32_t vs0 = max((im.sf >> 4) & 15u, 1u), vs1 = max((im.sf >> 12) & 15u, 1u), vs2 = max((im.sf >> 20) & 15u, 1u);
+    /* sample (x, y) of component c, in tile coordinates of that component */
+    auto smp = [&](uint32_t sb, uint32_t hs, uint32_t x, uint32_t y) -> uint32_t {
+        const uint32_t bx = x >> 3, m = bx / hs, h = bx - m * hs;
+        return *reinterpret_cast<const uint16_t *>(s_smp + sample_off(m, m * bpm + sb + (y >> 3) * hs + h, x, y));
+    };
+    const uint32_t bpp = g.rgba ? 4u : 3u;
+    /* The generic paths number the tile's quads (4 horizontally adjacent pixels) row-major;
+     * a lane takes quad lane, lane + 64, ... and tracks (row, quad-in-row) incrementally,
+     * so the loop has no division. */
+    const uint32_t quads = g.tile_w / 4;
+    const uint32_t dy = 64 / quads, dq = 64 - dy * quads;
+    uint32_t y = lane / quads;
+    uint32_t qx = lane - y * quads;
+    if (cl == MJ_CL_GREY) {
+        if (g.rgba) colour_grey<true>(s_smp, g, hs0, rgb, lane);
+        else colour_grey<false>(s_smp, g, hs0, rgb, lane);
         return;
     }
-    {
-        const uint32_t ch = im.hmax / im.comp[1].hsf, cv2 = im.vmax / im.comp[1].vsf;
-        const bool same = im.comp[1].hsf == 1 && im.comp[1].vsf == 1 && im.comp[2].hsf == 1 && im.comp[2].vsf == 1 &&
-                          im.comp[0].hsf == im.hmax && im.comp[0].vsf == im.vmax;
-        if (same && ch != 3 && cv2 <= 2) {
-            if (cv2 == 1) {
-                if (ch == 1) colour_fast<0, 0>(s_smp, s_tab, g, rgb);
-                else if (ch == 2) colour_fast<1, 0>(s_smp, s_tab, g, rgb);
-                else colour_fast<2, 0>(s_smp, s_tab, g, rgb);
-            } else {
-                if (ch == 1) colour_fast<0, 1>(s_smp, s_tab, g, rgb);
-                else if (ch == 2) colour_fast<1, 1>(s_smp, s_tab, g, rgb);
-                else colour_fast<2, 1>(s_smp, s_tab, g, rgb);
-            }
-            return;
-        }
+#define MJ_FAST(N, SH, SV)                                                \
+    case MJ_CL_FAST + N:                                                  \
+        if (g.rgba) colour_fast<SH, SV, true>(s_smp, s_tab, g, rgb, lane); \
+        else colour_fast<SH, SV, false>(s_smp, s_tab, g, rgb, lane);       \
+        return
+    switch (cl) {
+        MJ_FAST(0, 0, 0);
+        MJ_FAST(1, 1, 0);
+        MJ_FAST(2, 2, 0);
+        MJ_FAST(3, 0, 1);
+        MJ_FAST(4, 1, 1);
+        MJ_FAST(5, 2, 1);
+        default: break;
     }
+#undef MJ_FAST
     /* Source sample of output (i, j) in component c is (uint32)(ratio * i) with
      * ratio = (float) sf_c / max_sf (colour_conversion.c:44-45, :62-69).  Sampling
      * factors divide the maximum here, so that is i / (max_sf / sf_c). */
-    const uint32_t qh0 = im.hmax / im.comp[0].hsf, qh1 = im.hmax / im.comp[1].hsf, qh2 = im.hmax / im.comp[2].hsf;
-    const uint32_t qv0 = im.vmax / im.comp[0].vsf, qv1 = im.vmax / im.comp[1].vsf, qv2 = im.vmax / im.comp[2].vsf;
+    const uint32_t qh0 = hmax / hs0, qh1 = hmax / hs1, qh2 = hmax / hs2;
+    const uint32_t qv0 = vmax / vs0, qv1 = vmax / vs1, qv2 = vmax / vs2;
     for (; y < g.tile_h; y += dy, qx += dq) {
         if (qx >= quads) {
             qx -= quads;
@@ -578,10 +484,235 @@ __global__ __launch_bounds__(TPB, MJ_IDCT_WAVES) void mj_k_idct_colour(MjDeviceB
     }
 }
 
+/* row r of every block this lane works on in a tile of nblk blocks at src: all loads of a
+ * tile are issued at once */
+__device__ __forceinline__ void load_rows(const u4 *src, uint32_t nblk, uint32_t lane, u4 (&cv)[PASSES]) {
+#pragma unroll
+    for (int p = 0; p < PASSES; p++) {
+        cv[p] = (u4){0, 0, 0, 0};
+        if (p * 8 + (lane >> 3) < nblk) cv[p] = __builtin_nontemporal_load(src + p * 64 + lane);
+    }
+}
+
+/* the image's record, through the scalar cache */
+__device__ __forceinline__ MjIdctImg load_record(const MjDeviceBatch &b, uint32_t ii) {
+    return b.idct_img[ii];
+}
+
+__device__ __forceinline__ const u4 *tile_rows(const MjDeviceBatch &b, const MjIdctImg &d, uint32_t mrow, uint32_t m0) {
+    return reinterpret_cast<const u4 *>(b.coefs + (d.coef_off + ((uint64_t) mrow * d.mcus_x + m0) * (d.geo & 0xFFu)) * 64);
+}
+
+__global__ __launch_bounds__(TPB, MJ_IDCT_WAVES) void mj_k_idct_colour(MjDeviceBatch b) {
+    /* LDS: the two chroma tables, shared; per wavefront the tile's samples, the transpose
+     * buffers of the butterflies and the quantiser tables of the image it is working on */
+    __shared__ __align__(16) MjChromaTerm s_tab[512];
+    __shared__ __align__(16) uint8_t s_wave[WAVES][WAVE_BYTES];
+    static_assert(sizeof(MjChromaTable) == TPB * sizeof(MjChromaTerm), "one table row per thread");
+    s_tab[threadIdx.x] = c_chroma.t[threadIdx.x];
+    __syncthreads();       /* the only one: from here on every wavefront is on its own */
+
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint8_t *s_smp = s_wave[wave];
+    uint8_t *s_tr = s_smp + SMP_BYTES;
+    uint16_t (*s_qt)[64] = reinterpret_cast<uint16_t (*)[64]>(s_tr + TR_BYTES);
+    /* this wavefront's share: tiles t .. t_end - 1 of the batch, one contiguous run, so
+     * that it stays in one image (whose record it holds in scalar registers) and along one
+     * MCU row for as long as possible */
+    const uint32_t n_waves = gridDim.x * WAVES;
+    const uint32_t share = (b.n_idct_tiles + n_waves - 1) / n_waves;
+    uint32_t t = (blockIdx.x * WAVES + wave) * share;
+    const uint32_t t_end = min(t + share, b.n_idct_tiles);
+    if (t >= t_end) return;
+    uint32_t ii = 0;
+    MjIdctImg d = load_record(b, 0);
+    while (t >= d.first_tile + d.n_tiles) d = load_record(b, ++ii);
+    uint32_t mrow = (t - d.first_tile) / d.tiles_x;
+    uint32_t m0 = ((t - d.first_tile) - mrow * d.tiles_x) * ((d.geo >> 8) & 0xFFu);
+    u4 cv[PASSES];
+    load_rows(tile_rows(b, d, mrow, m0), min((d.geo >> 8) & 0xFFu, d.mcus_x - m0) * (d.geo & 0xFFu), threadIdx.x & 63u, cv);
+    uint32_t qt_of = 0xFFFFFFFFu;                        /* image whose quantiser tables are in s_qt */
+
+#if defined(MJ_IDCT_TRACE)
+    unsigned long long stamp_ = __builtin_amdgcn_s_memtime(), acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    for (;;) {
+        /* Per-lane values are derived again for every tile from a lane index the compiler
+         * cannot see through: hoisted out of the loop they would be held in registers (or
+         * spilled) across all of it, and they cost a handful of instructions. */
+        uint32_t lane = threadIdx.x & 63u;
+        asm volatile("" : "+v"(lane));
+        const uint32_t r = lane & 7u;                        /* the lane's row, then column, then row again */
+        const uint32_t grp = lane >> 3;                      /* block within the pass */
+        float *tr = reinterpret_cast<float *>(s_tr) + grp * TR_GROUP;
+        /* the reference scales the first row and the first column by 1/sqrt(2) before the
+         * butterflies (dct.c:164-167), the corner twice: lane 0 scales its whole row, the
+         * others multiply by one, which changes nothing */
+        constexpr SplitConst RS = split_const(0.707106781);
+        const SplitConst row_scale = {(r == 0) ? RS.hi : 1.0f, (r == 0) ? RS.lo : 0.0f};
+        /* where element j of a row sits after the row butterfly: 0 7 1 6 2 5 3 4 hold positions 0..7 */
+        const uint32_t tpos = (r < 4) ? 2 * r : 15 - 2 * r;
+        const MjIdctImg im = d;                              /* the current tile's image (d moves on to the next tile's below) */
+        const uint32_t cur_ii = ii, cur_mrow = mrow, cur_m0 = m0;
+        const uint32_t bpm = im.geo & 0xFFu, tile_mcus = (im.geo >> 8) & 0xFFu;
+        const uint32_t nm = min(tile_mcus, im.mcus_x - cur_m0), nblk = nm * bpm;
+        const uint32_t slot_comp = im.slot_comp;
+        if (qt_of != cur_ii) {
+            const MjImageDev &full = b.img[cur_ii];
+            for (uint32_t i = lane; i < MJ_MAX_COMP * 64; i += 64) s_qt[i >> 6][i & 63] = full.qt[i >> 6][i & 63];
+            qt_of = cur_ii;
+        }
+        /* a wavefront runs its LDS operations in order: what the colour stage of the tile
+         * before still reads is read before anything below is written */
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        MJ_STAMP(0);
+#if defined(MJ_IDCT_TRACE)
+        __builtin_amdgcn_s_waitcnt(0x0F70);   /* vmcnt(0): the tile's rows, and the stores of the tile before */
+        MJ_STAMP(1);
+#endif
+
+        /* ---- 1. eight lanes per block, eight blocks per pass -------------------- */
+        if (!(MJ_DBG(b) & 16u)) {
+            const float rcp_bpm = 1.0f / (float) bpm;
+#pragma unroll
+            for (int p = 0; p < PASSES; p++) {
+                const uint32_t blk = p * 8 + grp;
+                if (blk >= nblk) continue;                       /* whole groups of eight lanes drop out together */
+                /* blk + 0.5 over bpm is at least 0.05 away from an integer: the rounding of the
+                 * reciprocal and of the product cannot reach one */
+                const uint32_t mcu = (uint32_t) (((float) blk + 0.5f) * rcp_bpm);
+                const uint32_t slot = blk - mcu * bpm;
+                const uint32_t comp = (slot_comp >> (2 * slot)) & 3u;
+                float c[8];
+                {
+                    /* int16 wrap of the product (quant_table.c:137): the low halves of the 16-bit products */
+                    const us8 q = *reinterpret_cast<const us8 *>(&s_qt[comp][8 * r]);
+                    const us8 z = __builtin_bit_cast(us8, cv[p]);
+                    const us8 zq = z * q;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) c[j] = (float) (int16_t) zq[j];
+                }
+                c[0] = mulc(c[0], RS);                           /* first column */
+                /* first row, two values at a time, in the pairs the butterfly takes */
+                const f2 c04 = mulc((f2){c[0], c[4]}, row_scale), c17 = mulc((f2){c[1], c[7]}, row_scale);
+                const f2 c26 = mulc((f2){c[2], c[6]}, row_scale), c35 = mulc((f2){c[3], c[5]}, row_scale);
+                const Idct8Out ro = idct8<false>(c04, c17, c26, c35);
+                /* rows -> columns (the reference transposes, runs rows again, and transposes
+                 * back on the store: dct.c:173-193).  A row is stored in the order the
+                 * butterfly leaves it: 0 7 1 6 2 5 3 4. */
+                *reinterpret_cast<f2 *>(tr + r * 8) = ro.o07;
+                *reinterpret_cast<f2 *>(tr + r * 8 + 2) = ro.o16;
+                *reinterpret_cast<f2 *>(tr + r * 8 + 4) = ro.o25;
+                *reinterpret_cast<f2 *>(tr + r * 8 + 6) = ro.o34;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const float *col = tr + tpos;                    /* element r of every row */
+                const Idct8Out co = idct8<true>((f2){col[0], col[4 * 8]}, (f2){col[1 * 8], col[7 * 8]},
+                                                (f2){col[2 * 8], col[6 * 8]}, (f2){col[3 * 8], col[5 * 8]});
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                tr[0 * 8 + r] = co.o07.x;
+                tr[7 * 8 + r] = co.o07.y;
+                tr[1 * 8 + r] = co.o16.x;
+                tr[6 * 8 + r] = co.o16.y;
+                tr[2 * 8 + r] = co.o25.x;
+                tr[5 * 8 + r] = co.o25.y;
+                tr[3 * 8 + r] = co.o34.x;
+                tr[4 * 8 + r] = co.o34.y;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const float4 lo4 = *reinterpret_cast<const float4 *>(tr + r * 8), hi4 = *reinterpret_cast<const float4 *>(tr + r * 8 + 4);
+                /* row r of the samples */
+                *reinterpret_cast<uint4 *>(s_smp + sample_off(mcu, blk, 0, r)) =
+                    make_uint4(finish2(lo4.x, lo4.y), finish2(lo4.z, lo4.w), finish2(hi4.x, hi4.y), finish2(hi4.z, hi4.w));
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        MJ_STAMP(2);
+        /* the next tile's rows, on their way during the colour stage */
+        const bool more = ++t < t_end;
+        if (more) {
+            m0 += tile_mcus;
+            if (m0 >= im.mcus_x) {
+                m0 = 0;
+                mrow++;
+                if (t >= d.first_tile + d.n_tiles) {
+                    d = load_record(b, ++ii);
+                    mrow = 0;
+                }
+            }
+            load_rows(tile_rows(b, d, mrow, m0), min((d.geo >> 8) & 0xFFu, d.mcus_x - m0) * (d.geo & 0xFFu), lane, cv);
+        }
+        MJ_STAMP(3);
+
+        /* ---- optional: the padded component planes (Image.buf, decode.c:517-531) */
+        if (b.want_planes) {
+            const MjImageDev &full = b.img[cur_ii];
+            for (uint32_t i = lane; i < nblk * 8; i += 64) {
+                const uint32_t blk = i >> 3, row = i & 7u;
+                const uint32_t m = blk / bpm, slot = blk - m * bpm;
+                const uint32_t cc = full.blk_comp[slot];
+                const uint32_t hs = full.comp[cc].hsf, vs = full.comp[cc].vsf;
+                const uint64_t py = (uint64_t) cur_mrow * vs * 8 + full.blk_v[slot] * 8u + row;
+                const uint64_t px = ((uint64_t) (cur_m0 + m) * hs + full.blk_h[slot]) * 8;
+                const uint4 v = *reinterpret_cast<const uint4 *>(s_smp + sample_off(m, blk, 0, row));
+                *reinterpret_cast<uint2 *>(b.planes + full.comp[cc].plane_off + py * full.comp[cc].pw + px) =
+                    make_uint2(perm(v.y, v.x, 0x06040200u), perm(v.w, v.z, 0x06040200u));
+            }
+        }
+
+        /* ---- 2. upsample + colour ---------------------------------------------- */
+        if (!(MJ_DBG(b) & 8u)) {
+            const uint32_t hmax = (im.geo >> 16) & 0xFFu, vmax = im.geo >> 24;
+            TileGeo g;
+            g.bpm = bpm;
+            g.s0 = (im.cls >> 8) & 0xFFu;
+            g.s1 = (im.cls >> 16) & 0xFFu;
+            g.s2 = im.cls >> 24;
+            g.tile_w = nm * hmax * 8;
+            g.tile_h = vmax * 8;
+            g.px0 = cur_m0 * hmax * 8;
+            g.py0 = cur_mrow * g.tile_h;
+            g.X = im.X;
+            g.Y = im.Y;
+            g.pitch = im.pitch;
+            g.rgba = b.rgba != 0;
+            g.fold = (MJ_DBG(b) & 32u) != 0;
+            colour_tile(s_smp, s_tab, im, g, b.rgb + im.rgb_off, lane);
+        }
+        MJ_STAMP(4);
+#if defined(MJ_IDCT_TRACE)
+        acc_[7]++;
+#endif
+        if (!more) break;
+    }
+#if defined(MJ_IDCT_TRACE)
+    if ((threadIdx.x & 63u) == 0) {
+        for (int i = 0; i < 8; i++) atomicAdd(&b.stats[i], acc_[i]);
+    }
+#endif
+}
+
 }  // namespace
 
 hipError_t mj_launch_idct_colour(const MjDeviceBatch &b, hipStream_t s) {
-    if (b.n_idct_wg == 0) return hipSuccess;
-    hipLaunchKernelGGL(mj_k_idct_colour, dim3(b.n_idct_wg), dim3(TPB), 0, s, b);
+    if (b.n_idct_tiles == 0) return hipSuccess;
+    /* as many workgroups as the chip holds at once (three per compute unit, by their LDS) */
+    static int cus[64];
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (cus[dev] == 0) {
+        int n = 0;
+        e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess) return e;
+        cus[dev] = n > 0 ? n : 1;
+    }
+    const uint32_t resident = (uint32_t) cus[dev] * MJ_IDCT_WG_PER_CU;
+    const uint32_t need = (b.n_idct_tiles + WAVES - 1) / WAVES;
+    hipLaunchKernelGGL(mj_k_idct_colour, dim3(need < resident ? need : resident), dim3(TPB), 0, s, b);
     return hipGetLastError();
 }
