@@ -255,7 +255,8 @@ struct TileGeo {
     uint32_t px0, py0;                 /* the tile's first pixel in the image */
     uint32_t X, Y, pitch;
     bool rgba;
-    bool fold;                         /* timing experiments only */
+    bool fold, nostore;                /* timing experiments only */
+    uint32_t nostore_lane;
 };
 
 /*
@@ -358,6 +359,9 @@ __device__ __forceinline__ void colour_fast(const uint8_t *s_smp, const MjChroma
                     }
                     /* rows of one tile are at most a few megabytes apart: 32-bit offsets from the
                      * tile's first row */
+#if defined(MJ_EXPERIMENT)
+                    if (g.nostore && lane != g.nostore_lane) continue;   /* timing experiment: the arithmetic without the stores */
+#endif
                     store4<RGBA>(rgb_tile + ((__umul24(y + r, g.pitch) + bpp * (gx + 4 * h)) & fold_mask), cr8[0], cg8[0], cb8[0], cr8[1], cg8[1], cb8[1]);
                 }
             } else {
@@ -680,6 +684,8 @@ __global__ __launch_bounds__(TPB, MJ_IDCT_WAVES) void mj_k_idct_colour(MjDeviceB
             g.pitch = im.pitch;
             g.rgba = b.rgba != 0;
             g.fold = (MJ_DBG(b) & 32u) != 0;
+            g.nostore = (MJ_DBG(b) & 64u) != 0;
+            g.nostore_lane = 64u + (b.n_img >> 30);
             colour_tile(s_smp, s_tab, im, g, b.rgb + im.rgb_off, lane);
         }
         MJ_STAMP(4);
