@@ -530,7 +530,10 @@ def main():
             pvalue = ptot.pixels / ptot.elapsed_max / 1e6
             pms = 1e3 * ptot.elapsed_max / args.steps
             pk = {name: round(ms / max(n, 1), 4) for name, (ms, n) in pipe_res["kernels"].items()}
-            decode_ms = sum(pk.values())
+            # consecutive batches decode on two streams in turn: the per-kernel durations of this
+            # region include the time a kernel shares the chip with the neighbouring batch's, so the
+            # resident region's kernel times (above) are the yardstick for decode time alone
+            decode_ms = sum(k["avg_ms"] for k in kernels.values())
             out["pinned_host_to_hbm"] = {
                 "value": round(pvalue, 1), "unit": "MP/s", "ms_per_step": round(pms, 4),
                 "starts": "JPEG files in page-locked host memory", "ends": "RGB24 in HBM",
@@ -540,7 +543,8 @@ def main():
                 "host_wait_for_slot_ms_per_submit": round(pipe_res["host_wait_ms"], 4),
                 "submit_call_ms_incl_binding": round(pipe_res["python_submit_ms"], 4),
                 "h2d_copy_alone_ms": round(pipe_res["h2d_alone_ms"], 4),
-                "kernels_avg_ms": pk,
+                "kernels_avg_ms_while_overlapping_the_next_batch": pk,
+                "decode_streams": 2,
                 "ms_per_step_over_max_of_decode_and_copy": round(pms / max(decode_ms, pipe_res["h2d_alone_ms"], 1e-9), 3),
                 "fraction_of_resident_rate": round(pvalue / value, 3)}
             if pipe_res["parity_bad"] is not None:

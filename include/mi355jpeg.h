@@ -103,8 +103,10 @@ void mj_host_free(void *p);
  * reference's mmap -> decode_jpeg_buffer hand-off, jpeg_decoder.c:44-55, at batch
  * granularity).  mj_pipe_submit parses the files, enqueues the copy of their
  * entropy-coded bytes on the context's copy stream and the decode behind it on the
- * context's stream, and returns without waiting: the host work and the copy of batch
- * k + 1 run while batch k decodes.  `depth` batches are in flight at most; each has
+ * context's stream (consecutive batches alternate between that stream and a second one
+ * of the pipeline's, so that the tail of one decode overlaps the next, unless the caller
+ * has set a stream of its own with mj_set_stream), and returns without waiting: the host
+ * work and the copy of batch k + 1 run while batch k decodes.  `depth` batches are in flight at most; each has
  * its own device memory, allocated on first use and reused from then on.  *out is
  * owned by the pipeline and is recycled by the depth-th submit after it (that submit
  * waits for its decode first): read results (mj_batch_sync, mj_batch_device_rgb,

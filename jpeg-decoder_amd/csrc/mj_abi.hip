@@ -152,6 +152,7 @@ struct mj_pipe {
     mj_ctx *ctx = nullptr;
     uint32_t flags = 0;
     std::vector<mj_batch *> slots;
+    hipStream_t alt = nullptr;         /* second decode stream: consecutive batches alternate (see mj_pipe_submit) */
     uint64_t next = 0;
     double wait_ms = 0, host_ms = 0;   /* per submit: waiting for the slot; parse + layout + enqueue */
 };
@@ -925,6 +926,11 @@ int mj_pipe_create(mj_ctx *ctx, int depth, uint32_t flags, mj_pipe **out) {
         }
         p->slots.push_back(b);
     }
+    if (hipStreamCreateWithFlags(&p->alt, hipStreamNonBlocking) != hipSuccess) {
+        for (mj_batch *s : p->slots) batch_free(s, false);
+        delete p;
+        return set_err("mj_pipe_create: cannot create the second decode stream");
+    }
     *out = p;
     return 0;
 }
@@ -937,6 +943,7 @@ void mj_pipe_destroy(mj_pipe *p) {
         if (b->stream) (void) hipStreamSynchronize(b->stream);
         batch_free(b, false);
     }
+    if (p->alt) (void) hipStreamDestroy(p->alt);
     delete p;
 }
 
@@ -954,7 +961,12 @@ int mj_pipe_submit(mj_pipe *p, const uint8_t *const *bufs, const size_t *lens, i
     MjPrep prep;
     if (prepare(bufs, lens, n, prep, "mj_pipe_submit")) return -1;
     if (fill_own(b, prep, p->flags, true, false) != 0) return -1;
-    if (enqueue_decode(b, ctx->stream) != 0) return -1;
+    /* Consecutive batches decode on two streams in turn: the last synchronisation rounds and
+     * the ends of the other kernels of one batch, which leave most of the chip idle, run
+     * beside the kernels of the next.  Batches are independent (each slot has its own device
+     * memory); a caller who has put the context on a stream of its own keeps strict order. */
+    hipStream_t s = (ctx->stream == ctx->own && (p->next & 1u)) ? p->alt : ctx->stream;
+    if (enqueue_decode(b, s) != 0) return -1;
     const clk::time_point t2 = clk::now();
     p->wait_ms += std::chrono::duration<double, std::milli>(t1 - t0).count();
     p->host_ms += std::chrono::duration<double, std::milli>(t2 - t1).count();

@@ -89,9 +89,10 @@ hipError_t mj_launch_idct_colour(const MjDeviceBatch &b, hipStream_t s);
  * MJ_IDCT_TILE_BLOCKS blocks (eight lanes work on a block: three passes of eight blocks). */
 #define MJ_IDCT_THREADS 512
 #define MJ_IDCT_TILE_BLOCKS 24
+#define MJ_IDCT_TILE_MCUS_MAX 16
 static inline __host__ __device__ uint32_t mj_idct_tile_mcus(uint32_t bpm) {
     const uint32_t t = MJ_IDCT_TILE_BLOCKS / (bpm ? bpm : 1u);
-    return t ? t : 1u;
+    return t > MJ_IDCT_TILE_MCUS_MAX ? MJ_IDCT_TILE_MCUS_MAX : (t ? t : 1u);
 }
 
 #endif

@@ -44,10 +44,18 @@ constexpr int TPB = MJ_IDCT_THREADS;
 constexpr int WAVES = TPB / 64;                /* independent wavefronts per workgroup */
 constexpr int MAXB = MJ_IDCT_TILE_BLOCKS;      /* blocks per tile */
 constexpr int PASSES = (MAXB + 7) / 8;         /* eight blocks per pass */
-constexpr int TR_GROUP = 72;                   /* floats per 8x8 transpose buffer: 64 + 8, conflict-free strided access */
+/* The 8x8 transpose buffer of a block: rows ten floats apart, blocks eighty.  With that the
+ * eight-byte row accesses of the eight lanes of two neighbouring blocks (one LDS pass of
+ * sixteen lanes) fall on sixteen different bank pairs, and so do those of four blocks on
+ * the 64-bank read path; the four-byte column accesses of a block are eight consecutive
+ * banks, two-way shared between blocks g and g + 2, which a store hides and a load pays
+ * with one cycle. */
+constexpr int TR_ROW = 10;
+constexpr int TR_GROUP = 8 * TR_ROW;
 constexpr int TR_BYTES = 8 * TR_GROUP * 4;     /* per wavefront */
-constexpr int SMP_BYTES = MAXB * 128 + MAXB * 16;   /* per wavefront: 128 bytes per block, 16 between MCUs */
-constexpr int QT_BYTES = MJ_MAX_COMP * 64 * 2; /* per wavefront: the quantiser tables of its image */
+constexpr int SMP_BYTES = MAXB * 128 + MJ_IDCT_TILE_MCUS_MAX * 16;   /* per wavefront: 128 bytes per block, 16 between MCUs */
+constexpr int QT_COMPS = 3;                    /* images of more components are refused when the batch is built */
+constexpr int QT_BYTES = QT_COMPS * 64 * 2;    /* per wavefront: the quantiser tables of its image */
 constexpr int WAVE_BYTES = SMP_BYTES + TR_BYTES + QT_BYTES;
 static_assert(3 * (WAVES * WAVE_BYTES + 512 * 8) <= 160 * 1024, "three workgroups per compute unit");
 constexpr uint32_t BLK_BYTES = 128;            /* a block of samples in LDS: 8 rows of 8 x 16 bits */
@@ -563,7 +571,7 @@ __global__ __launch_bounds__(TPB, MJ_IDCT_WAVES) void mj_k_idct_colour(MjDeviceB
         const uint32_t slot_comp = im.slot_comp;
         if (qt_of != cur_ii) {
             const MjImageDev &full = b.img[cur_ii];
-            for (uint32_t i = lane; i < MJ_MAX_COMP * 64; i += 64) s_qt[i >> 6][i & 63] = full.qt[i >> 6][i & 63];
+            for (uint32_t i = lane; i < QT_COMPS * 64; i += 64) s_qt[i >> 6][i & 63] = full.qt[i >> 6][i & 63];
             qt_of = cur_ii;
         }
         /* a wavefront runs its LDS operations in order: what the colour stage of the tile
@@ -605,31 +613,32 @@ __global__ __launch_bounds__(TPB, MJ_IDCT_WAVES) void mj_k_idct_colour(MjDeviceB
                 /* rows -> columns (the reference transposes, runs rows again, and transposes
                  * back on the store: dct.c:173-193).  A row is stored in the order the
                  * butterfly leaves it: 0 7 1 6 2 5 3 4. */
-                *reinterpret_cast<f2 *>(tr + r * 8) = ro.o07;
-                *reinterpret_cast<f2 *>(tr + r * 8 + 2) = ro.o16;
-                *reinterpret_cast<f2 *>(tr + r * 8 + 4) = ro.o25;
-                *reinterpret_cast<f2 *>(tr + r * 8 + 6) = ro.o34;
+                *reinterpret_cast<f2 *>(tr + r * TR_ROW) = ro.o07;
+                *reinterpret_cast<f2 *>(tr + r * TR_ROW + 2) = ro.o16;
+                *reinterpret_cast<f2 *>(tr + r * TR_ROW + 4) = ro.o25;
+                *reinterpret_cast<f2 *>(tr + r * TR_ROW + 6) = ro.o34;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 const float *col = tr + tpos;                    /* element r of every row */
-                const Idct8Out co = idct8<true>((f2){col[0], col[4 * 8]}, (f2){col[1 * 8], col[7 * 8]},
-                                                (f2){col[2 * 8], col[6 * 8]}, (f2){col[3 * 8], col[5 * 8]});
+                const Idct8Out co = idct8<true>((f2){col[0], col[4 * TR_ROW]}, (f2){col[1 * TR_ROW], col[7 * TR_ROW]},
+                                                (f2){col[2 * TR_ROW], col[6 * TR_ROW]}, (f2){col[3 * TR_ROW], col[5 * TR_ROW]});
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                tr[0 * 8 + r] = co.o07.x;
-                tr[7 * 8 + r] = co.o07.y;
-                tr[1 * 8 + r] = co.o16.x;
-                tr[6 * 8 + r] = co.o16.y;
-                tr[2 * 8 + r] = co.o25.x;
-                tr[5 * 8 + r] = co.o25.y;
-                tr[3 * 8 + r] = co.o34.x;
-                tr[4 * 8 + r] = co.o34.y;
+                tr[0 * TR_ROW + r] = co.o07.x;
+                tr[7 * TR_ROW + r] = co.o07.y;
+                tr[1 * TR_ROW + r] = co.o16.x;
+                tr[6 * TR_ROW + r] = co.o16.y;
+                tr[2 * TR_ROW + r] = co.o25.x;
+                tr[5 * TR_ROW + r] = co.o25.y;
+                tr[3 * TR_ROW + r] = co.o34.x;
+                tr[4 * TR_ROW + r] = co.o34.y;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                const float4 lo4 = *reinterpret_cast<const float4 *>(tr + r * 8), hi4 = *reinterpret_cast<const float4 *>(tr + r * 8 + 4);
+                const f2 *row = reinterpret_cast<const f2 *>(tr + r * TR_ROW);
+                const f2 s01 = row[0], s23 = row[1], s45 = row[2], s67 = row[3];
                 /* row r of the samples */
                 *reinterpret_cast<uint4 *>(s_smp + sample_off(mcu, blk, 0, r)) =
-                    make_uint4(finish2(lo4.x, lo4.y), finish2(lo4.z, lo4.w), finish2(hi4.x, hi4.y), finish2(hi4.z, hi4.w));
+                    make_uint4(finish2(s01.x, s01.y), finish2(s23.x, s23.y), finish2(s45.x, s45.y), finish2(s67.x, s67.y));
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             }
