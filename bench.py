@@ -112,12 +112,38 @@ def generate(workload, seeds, workers):
         return pool.map(_gen_one, jobs, chunksize=1)
 
 
+def _in_child(fn, *args):
+    """fn(*args) in a forked child; None if the child died (the compiled reference walks off
+    its buffers on some streams, see REFERENCE_UNUSABLE and reference_survives)."""
+    import pickle
+    r, w = os.pipe()
+    pid = os.fork()
+    if pid == 0:
+        code = 1
+        try:
+            os.close(r)
+            with os.fdopen(w, "wb") as f:
+                pickle.dump(fn(*args), f)
+            code = 0
+        finally:
+            os._exit(code)
+    os.close(w)
+    with os.fdopen(r, "rb") as f:
+        blob = f.read()
+    _, status = os.waitpid(pid, 0)
+    if status != 0 or not blob:
+        return None
+    return pickle.loads(blob)
+
+
 def _cpu_worker(args):
     kind, data, iters = args
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from refbind import Oracle, Ref
-    lib = Ref() if kind == "reference" else Oracle()
-    return lib.time_decode(data, iters)
+    if kind == "reference":
+        t = _in_child(lambda: Ref().time_decode(data, iters))
+        return t if t is not None else -1.0
+    return Oracle().time_decode(data, iters)
 
 
 # Workloads the compiled reference cannot be the checker or the CPU baseline for: C4 (its
@@ -143,6 +169,20 @@ def cpu_baseline(files, pixels, workload, max_cores=16, seconds=10.0):
     except AttributeError:
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, max_cores, len(files)))
+    if kind == "reference":
+        # only files the compiled reference gets through (it dies on some streams with restart
+        # markers, bitstream.c:84-176): the first `cores` such files
+        ok = []
+        for i, f in enumerate(files):
+            if _in_child(lambda: Ref().decode(f, want_tap=False) is not None):
+                ok.append(i)
+                if len(ok) == cores:
+                    break
+        if not ok:
+            kind, ok = ("port", list(range(len(files)))) if Oracle.available() else (None, [])
+        if kind is None:
+            return None
+        files, pixels = [files[i] for i in ok], [pixels[i] for i in ok]
     # about 50 MP/s per core: size every core's sample to `seconds`
     iters = [min(4096, max(1, int(seconds * 50e6 / max(pixels[i % len(files)], 1)))) for i in range(cores)]
     jobs = [(kind, files[i % len(files)], iters[i]) for i in range(cores)]
@@ -162,12 +202,22 @@ def cpu_baseline(files, pixels, workload, max_cores=16, seconds=10.0):
 
 
 def _digest_worker(args):
+    """(sha256 of coefficients, sha256 of RGB, checker that produced them).  The compiled
+    reference decodes in a child of its own: on some streams with restart markers it reads
+    a partly consumed FF byte as a marker (bitstream.c:84-176), walks into the marker bytes
+    and dies; the CPU restatement then stands in for that file."""
     kind, data = args
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from refbind import Oracle, Ref
-    lib = Ref() if kind == "reference" else Oracle()
-    want = lib.decode(data)
-    return hashlib.sha256(want.coefs.tobytes()).hexdigest(), hashlib.sha256(want.rgb.tobytes()).hexdigest()
+
+    def digests(lib):
+        want = lib.decode(data)
+        return hashlib.sha256(want.coefs.tobytes()).hexdigest(), hashlib.sha256(want.rgb.tobytes()).hexdigest()
+    if kind == "reference":
+        got = _in_child(lambda: digests(Ref()))
+        if got is not None:
+            return got[0], got[1], "reference"
+    return digests(Oracle()) + ("port",)
 
 
 def checker_digests(files, workers, workload):
@@ -189,10 +239,38 @@ def checker_digests(files, workers, workload):
         return kind, pool.map(_digest_worker, jobs, chunksize=1)
 
 
+def checked_by(digests):
+    """how many files each checker vouched for"""
+    out = {}
+    for d in digests:
+        out[d[2]] = out.get(d[2], 0) + 1
+    return out
+
+
+def single_image_ms(ctx, data, flags, reps=30):
+    """Steady-state milliseconds of one image on its own: batch set-up on the host (parse,
+    flattening, layout, upload), and the decode from launch to the RGB being in HBM."""
+    import torch
+    t_create = t_decode = 0.0
+    for i in range(reps + 3):
+        t0 = time.perf_counter()
+        b = ctx.batch([data], flags)
+        t1 = time.perf_counter()
+        b.decode()
+        b.sync()
+        t2 = time.perf_counter()
+        b.close()
+        if i >= 3:
+            t_create += t1 - t0
+            t_decode += t2 - t1
+    torch.cuda.synchronize()
+    return {"set_up_ms": round(1e3 * t_create / reps, 3), "decode_ms": round(1e3 * t_decode / reps, 3)}
+
+
 def parity_of(batch, digests):
     """(images with differing coefficients, images with differing RGB) of a decoded batch."""
     bad_c = bad_r = 0
-    for i, (dc, dr) in enumerate(digests):
+    for i, (dc, dr, _) in enumerate(digests):
         bad_c += hashlib.sha256(batch.coefs(i).tobytes()).hexdigest() != dc
         bad_r += hashlib.sha256(batch.rgb(i).tobytes()).hexdigest() != dr
     return bad_c, bad_r
@@ -267,6 +345,7 @@ def main():
                     help="distinct batches per GPU the pipelined region cycles through (every step re-parses and re-uploads)")
     ap.add_argument("--depth", type=int, default=3, help="batches in flight in the pipelined region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-singles", action="store_true", help="skip the single-image latency figures (single_image in the output)")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the pinned-host -> HBM region")
     ap.add_argument("--parity", default="all", choices=["all", "one", "none"],
                     help="check every image of the timed batch against the checker, one image, or nothing")
@@ -394,8 +473,15 @@ def main():
     if digests is not None and n_streams == 1:
         bad_c, bad_r = parity_of(batches[0], digests)
         mismatched += bad_c + bad_r
-        parity = {"checker": checker, "images_checked": len(digests), "images_with_coefficient_mismatch": bad_c,
-                  "images_with_rgb_mismatch": bad_r, "how": "SHA-256 of every image's coefficient blocks and RGB"}
+        parity = {"checker": checker, "images_checked": len(digests), "checked_by": checked_by(digests),
+                  "images_with_coefficient_mismatch": bad_c, "images_with_rgb_mismatch": bad_r,
+                  "how": "SHA-256 of every image's coefficient blocks and RGB; the CPU restatement stands in for "
+                         "files on which the compiled reference dies"}
+    singles = None
+    if rank == 0 and not args.no_singles:
+        # latency of small work: one image alone (nothing to overlap its kernels with)
+        singles = {"C1 (512x512 4:2:0, no restart markers)": single_image_ms(ctxs[0], J.synth.config_jpeg("C1", 0), 0),
+                   "C4 (7680x4320 4:2:0, no restart markers)": single_image_ms(ctxs[0], J.synth.config_jpeg("C4", 0), 0, reps=10)}
     for bt in batches:
         bt.close()
     for c in ctxs:
@@ -522,6 +608,7 @@ def main():
             "end_to_end_hbm": {"algorithmic_bytes_per_px": round(e2e_bytes_px, 3),
                                "frac_of_peak": round(e2e_bytes_px * value * 1e6 / world / (HBM_PEAK_GBS * 1e9), 4)},
             "kernels": kernels,
+            "single_image": singles,
             "kernels_max_over_ranks_ms": {k: round(v, 4) for k, v in kernel_ms_max.items()},
             "host": {"generate_s": round(t_gen, 2), "one_shot_batch_create_s": round(t_prepare, 4),
                      "first_batch_create_s": round(t_prepare_first, 4)},
