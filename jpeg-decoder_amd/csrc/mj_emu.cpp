@@ -170,9 +170,10 @@ int64_t mj_emu_decode_coefs(const uint8_t *file, size_t len, int16_t *coefs, int
     wcx.pair_stride = (uint32_t) sizeof(MjHuffPair);
 
     int64_t st_subs = 0, st_rounds = 0, st_maxr = 0, st_seqs = 0, st_multi = 0, st_fix = 0, st_tasks = 0;
-    // MJ_EMU_HIST=1: print, per round, how many decoders are still out of step
+    // MJ_EMU_HIST=1: print, per round, how many decoders are still out of step and by which part of the state
     int64_t hist_store[64] = {0};
     int64_t *hist = getenv("MJ_EMU_HIST") ? hist_store : nullptr;
+    int64_t mism[32][3] = {{0}};
 
     struct Task {
         uint32_t m;   // subsequence to decode next (index within the interval)
@@ -220,6 +221,11 @@ int64_t mj_emu_decode_coefs(const uint8_t *file, size_t len, int16_t *coefs, int
                 for (const Task &t : tasks) {
                     const Rec out = span(cx, t.from.p, t.from.k, t.from.c, sub_end(t.m));
                     const bool synced = same_state(out, rec[t.m]);
+                    if (hist && !synced && rounds < 32) {
+                        /* which part of the state differs: bit position; else zigzag index; else block slot */
+                        const int what = out.p != rec[t.m].p ? 0 : (out.k != rec[t.m].k ? 1 : 2);
+                        mism[rounds][what]++;
+                    }
                     rec[t.m] = out;
                     if (!synced && t.m + 1 < first + n) next.push_back(Task{t.m + 1, out});
                 }
@@ -305,7 +311,8 @@ int64_t mj_emu_decode_coefs(const uint8_t *file, size_t len, int16_t *coefs, int
     }
     if (hist) {
         for (int r = 1; r < 32 && hist[32 + r]; r++) {
-            fprintf(stderr, "round %d: %lld decoders in %lld sequences\n", r, (long long) hist[r], (long long) hist[32 + r]);
+            fprintf(stderr, "round %d: %lld decoders in %lld sequences; still out of step by bit position %lld, by zigzag index only %lld, by block slot only %lld\n",
+                    r, (long long) hist[r], (long long) hist[32 + r], (long long) mism[r][0], (long long) mism[r][1], (long long) mism[r][2]);
         }
     }
     if (stats) {

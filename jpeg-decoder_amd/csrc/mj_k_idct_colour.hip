@@ -22,11 +22,12 @@
  *      saturating pack, and 24-byte stores of RGB24.
  * Wavefronts are persistent and independent of each other -- no workgroup barrier after
  * the start -- so at any time some are in the arithmetic of step 1 while others wait
- * for their stores of step 2, and the load on HBM is even.  Every wavefront takes tiles
- * w, w + W, w + 2W, ... (W wavefronts on the chip); the four wavefronts next to each other
- * write neighbouring 192-byte pieces of the same RGB rows.  The coefficient rows of a
- * wavefront's next tile are requested as soon as the butterflies have consumed the
- * current ones and arrive during the colour stage.
+ * for their stores of step 2, and the load on HBM is even.  Every wavefront takes one
+ * contiguous run of the batch's tiles (it walks along MCU rows, so the 192-byte pieces it
+ * writes to an RGB row complete each other's cache lines, and it keeps the 64-byte record
+ * of its image in scalar registers until the run crosses into the next image).  The
+ * coefficient rows of a wavefront's next tile are requested as soon as the butterflies
+ * have consumed the current ones and arrive during the colour stage.
  *
  * The IDCT arithmetic follows the reference's rounding points exactly: float storage,
  * double constants, no fused multiply-add (the file is compiled with
