@@ -307,7 +307,8 @@ static void put_dht(BW *w, int tc_th, const uint8_t *bits, const uint8_t *vals) 
  * hs, vs: luma sampling factors (chroma is 1x1): 1,1 = 4:4:4; 2,1 = 4:2:2;
  *         2,2 = 4:2:0; 1,2 = 4:4:0; 4,1 = 4:1:1.  Ignored for grey.
  * ri: restart interval in MCUs (0 = no DRI segment, no RST markers).
- * flags: bit 0 = fit the Huffman tables to the image instead of using the Annex K ones.
+ * flags: bit 0 = fit the Huffman tables to the image instead of using the Annex K ones;
+ *        bit 1 = the three bytes of a pixel are Y, Cb, Cr already (no colour conversion).
  * Returns the number of bytes the stream needs; it is complete only if that is
  * <= cap.  Negative on bad arguments.
  */
@@ -352,6 +353,12 @@ int64_t mjs_encode2(const uint8_t *pix, int W, int H, int ncomp, int hs, int vs,
                 Yp[(size_t) y * PW + x] = p[0];
             } else {
                 int r = p[0], g = p[1], b = p[2];
+                if (flags & 2) {
+                    Yp[(size_t) y * PW + x] = p[0];
+                    fcb[(size_t) y * PW + x] = p[1];
+                    fcr[(size_t) y * PW + x] = p[2];
+                    continue;
+                }
                 /* JFIF full-range BT.601, 16-bit fixed point */
                 Yp[(size_t) y * PW + x] = (uint8_t) ((19595 * r + 38470 * g + 7471 * b + 32768) >> 16);
                 fcb[(size_t) y * PW + x] = (uint8_t) ((-11059 * r - 21709 * g + 32768 * b + (128 << 16) + 32767) >> 16);

@@ -46,3 +46,30 @@ def ref():
     if not Ref.available():
         pytest.skip("oracle/_ref/libjpegref.so absent (built only where /root/reference exists)")
     return Ref()
+
+
+def ycc_neighbourhood_jpeg(sampling):
+    """A quality-100 file of flat MCUs whose (Y, Cb, Cr) sweep the neighbourhood of
+    (219, 228, 28): the one triple whose green sum is exactly -256, which the reference's
+    uint8 store turns into 0 instead of clamping (colour_conversion.c:71-79).  Returns the file."""
+    import numpy as np
+    import jpeg_decoder_amd as J
+    m = 8 if sampling == "4:4:4" else 16
+    combos = [(y, cb, cr) for y in range(214, 226) for cb in range(225, 232) for cr in range(25, 32)]
+    cols = 28
+    rows = (len(combos) + cols - 1) // cols
+    img = np.zeros((rows * m, cols * m, 3), np.uint8)
+    for i, t in enumerate(combos):
+        r, c = divmod(i, cols)
+        img[r * m:(r + 1) * m, c * m:(c + 1) * m] = t
+    return J.synth.encode_jpeg(img, sampling, 100, 0, ycc=True)
+
+
+def wrap_triple_pixels(planes, sampling):
+    """Boolean mask of the luma plane where the decoded samples are (219, 228, 28)."""
+    import numpy as np
+    cb, cr = planes[1], planes[2]
+    if sampling != "4:4:4":
+        cb = np.repeat(np.repeat(cb, 2, 0), 2, 1)
+        cr = np.repeat(np.repeat(cr, 2, 0), 2, 1)
+    return (planes[0] == 219) & (cb == 228) & (cr == 28)

@@ -11,7 +11,7 @@ import pytest
 
 import jpeg_decoder_amd as J
 from jpeg_decoder_amd import binding
-from conftest import PARITY_FIXTURES, load_fixture
+from conftest import PARITY_FIXTURES, load_fixture, wrap_triple_pixels, ycc_neighbourhood_jpeg
 
 pytestmark = pytest.mark.gpu
 
@@ -106,6 +106,29 @@ def test_synthetic_vs_oracle(ctx, oracle, case):
     b = ctx.batch([data], binding.MJ_WANT_PLANES)
     b.decode()
     _check_image(b, 0, o.coefs, o.planes, o.rgb, str(case))
+    b.close()
+
+
+@pytest.mark.parametrize("sampling", ["4:4:4", "4:2:0"])
+@pytest.mark.parametrize("rgba", [0, binding.MJ_OUT_RGBA])
+def test_green_that_wraps_to_zero_like_the_reference(ctx, oracle, sampling, rgba):
+    """Flat MCUs around (Y, Cb, Cr) = (219, 228, 28): the one triple whose green wraps to 0
+    in the reference (colour_conversion.c:71-79), with its clamped neighbours, on the
+    vector path (interior) of the colour step."""
+    data = ycc_neighbourhood_jpeg(sampling)
+    o = oracle.decode(data)
+    hit = wrap_triple_pixels(o.planes, sampling)
+    assert hit.sum() >= 64, "the file no longer holds the wrapping triple"
+    assert set(o.rgb[hit][:, 1].tolist()) == {0}
+    b = ctx.batch([data], binding.MJ_WANT_PLANES | rgba)
+    b.decode()
+    assert b.status(0) == 0
+    for c, p in enumerate(o.planes):
+        assert np.array_equal(b.plane(0, c), p), f"plane {c}"
+    out = b.rgb(0)
+    assert np.array_equal(out[..., :3], o.rgb)
+    if rgba:
+        assert (out[..., 3] == 255).all()
     b.close()
 
 

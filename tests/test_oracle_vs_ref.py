@@ -125,3 +125,15 @@ def test_oracle_equals_reference_on_fitted_tables(oracle, ref, mode, q, opt):
     a, b, c = ref.decode(data), oracle.decode(data), oracle.decode(std)
     assert np.array_equal(a.coefs, b.coefs) and np.array_equal(a.rgb, b.rgb)
     assert np.array_equal(b.coefs, c.coefs) and np.array_equal(b.rgb, c.rgb)      # the tables change the bytes, not the picture
+
+
+@pytest.mark.parametrize("sampling", ["4:4:4", "4:2:0"])
+def test_oracle_equals_reference_where_green_wraps(oracle, ref, sampling):
+    """A whole file whose decoded samples reach (219, 228, 28), the triple whose green the
+    reference's uint8 store wraps to 0 (colour_conversion.c:71-79): both agree end to end."""
+    from conftest import wrap_triple_pixels, ycc_neighbourhood_jpeg
+    data = ycc_neighbourhood_jpeg(sampling)
+    o, r = oracle.decode(data), ref.decode(data)
+    assert np.array_equal(o.coefs, r.coefs) and np.array_equal(o.rgb, r.rgb)
+    hit = wrap_triple_pixels(o.planes, sampling)
+    assert hit.sum() >= 64 and set(r.rgb[hit][:, 1].tolist()) == {0}
