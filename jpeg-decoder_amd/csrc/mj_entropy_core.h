@@ -293,17 +293,17 @@ struct MjSym {
     bool done;        /* the block ended with this step */
 };
 
-/* A first-level entry that is not a code: second-level table or canonical walk. */
-MJ_HD uint32_t mj_long_code(const MjScanCtx &cx, const MjLane &L, uint32_t e) {
-    const MjHuffDev *H = reinterpret_cast<const MjHuffDev *>(cx.tabs + L.tcur);
-    const uint32_t w = L.hi >> 16;
+/* A first-level entry that is not a code: second-level table or canonical walk.  tcur is the
+ * byte offset of the table in use, hi the stream from the symbol's first bit on. */
+MJ_HD uint32_t mj_long_code_at(const MjScanCtx &cx, uint32_t tcur, uint32_t hi, int is_ac, uint32_t e) {
+    const MjHuffDev *H = reinterpret_cast<const MjHuffDev *>(cx.tabs + tcur);
+    const uint32_t w = hi >> 16;
     if (e & MJ_LUT_LONG) {
         /* the MJ_SUB_BITS bits after the first MJ_LUT_BITS index the second level */
         return H->sub[e & (MJ_SUB_MAX - 1)][w & (MJ_SUB_SIZE - 1)];
     }
     /* canonical ranges per length (the reference's own walk, decode.c:674-681) */
-    const MjHuffWalk *W = cx.walk + L.tcur / (uint32_t) sizeof(MjHuffDev);
-    const int is_ac = L.k != 0;
+    const MjHuffWalk *W = cx.walk + tcur / (uint32_t) sizeof(MjHuffDev);
     for (uint32_t l = MJ_LUT_BITS + 1; l <= 16; l++) {
         const int32_t code = (int32_t) (w >> (16 - l));
         if (code <= W->maxcode[l]) {
@@ -311,6 +311,9 @@ MJ_HD uint32_t mj_long_code(const MjScanCtx &cx, const MjLane &L, uint32_t e) {
         }
     }
     return mj_lut_entry(16, 0, is_ac);   /* no such code: 16 bits are consumed as an end-of-block */
+}
+MJ_HD uint32_t mj_long_code(const MjScanCtx &cx, const MjLane &L, uint32_t e) {
+    return mj_long_code_at(cx, L.tcur, L.hi, L.k != 0, e);
 }
 
 /*

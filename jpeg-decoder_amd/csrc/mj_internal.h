@@ -84,6 +84,24 @@ hipError_t mj_launch_entropy_write(const MjDeviceBatch &b, hipStream_t s);
 hipError_t mj_launch_entropy_serial(const MjDeviceBatch &b, hipStream_t s);
 hipError_t mj_launch_idct_colour(const MjDeviceBatch &b, hipStream_t s);
 
+/* Compute units of the current device (asked once per device). */
+static inline hipError_t mj_device_cus(uint32_t *out) {
+    static int cus[64];
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    int n = __atomic_load_n(&cus[dev], __ATOMIC_RELAXED);
+    if (n == 0) {
+        e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess) return e;
+        if (n <= 0) n = 1;
+        __atomic_store_n(&cus[dev], n, __ATOMIC_RELAXED);
+    }
+    *out = (uint32_t) n;
+    return hipSuccess;
+}
+
 /* Tile geometry of the IDCT kernel (host + device).  A tile is a run of consecutive MCUs
  * of one MCU row that one wavefront takes from coefficients to RGB: at most
  * MJ_IDCT_TILE_BLOCKS blocks (eight lanes work on a block: three passes of eight blocks). */

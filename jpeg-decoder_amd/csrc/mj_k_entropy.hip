@@ -49,8 +49,16 @@ namespace {
 
 constexpr int WAVES = 4;             /* writing, serial kernels */
 constexpr int TPB = WAVES * 64;
-constexpr int SYNC_WAVES = MJ_WG_SEQS;
-constexpr int SYNC_TPB = SYNC_WAVES * 64;
+/* The synchronisation kernel comes in two shapes.  SPW = 1: a sequence per wavefront, eight
+ * wavefronts per workgroup, a lane takes the subsequences a lane of the writing pass takes.
+ * SPW = 2: a sequence per half wavefront, four wavefronts per workgroup, a lane takes twice
+ * as many subsequences in the cold pass; half as many decoders have to go on into the
+ * rounds, and five workgroups fit a CU (by their LDS) instead of four (by their
+ * wavefronts), so that all the workgroups of a large batch are on the chip from the start
+ * instead of the last of them starting when the first have finished.  A batch too small to
+ * fill the chip is bound by the time a lane takes and keeps the short lanes.  The records
+ * are per subsequence, so the two passes need not agree on the lanes. */
+constexpr int SYNC_TPB_MAX = MJ_WG_SEQS * 64;
 
 struct Geo {          /* wave-uniform geometry of one interval */
     uint32_t b0, b1;  /* bit range in the compacted stream */
@@ -216,22 +224,25 @@ __device__ __forceinline__ void push_task(bool have, uint32_t task, uint32_t *qu
     if (have) queue[base + __popcll(mask & ((1ull << lane) - 1ull))] = task;
 }
 
-__global__ __launch_bounds__(SYNC_TPB, 8) void mj_k_entropy_sync(MjDeviceBatch b) {
+template <int SYNC_SPW>
+__global__ __launch_bounds__(MJ_WG_SEQS * 64 / SYNC_SPW, SYNC_SPW == 2 ? 5 : 8) void mj_k_entropy_sync(MjDeviceBatch b) {
+    constexpr int SYNC_SEQ_LANES = MJ_SEQ_LANES / SYNC_SPW;
+    constexpr int SYNC_TPB = MJ_WG_SEQS * 64 / SYNC_SPW;
     const uint32_t ii = b.wg_img[blockIdx.x];
     const MjImageDev &im = b.img[ii];
     const uint32_t n_seq = b.dyn[ii].n_seq;
-    const uint32_t seq0 = (blockIdx.x - im.wg_first) * SYNC_WAVES;
+    const uint32_t seq0 = (blockIdx.x - im.wg_first) * MJ_WG_SEQS;
     if (seq0 >= n_seq) return;
 
     /* dynamic LDS: [tables][sequence geometry][3 queue counters][queue][symbol-run tables] */
     SeqGeo *s_geo = reinterpret_cast<SeqGeo *>(lds_after_dc(b, 0));
-    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_geo + SYNC_WAVES);
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_geo + MJ_WG_SEQS);
     uint32_t *s_queue = s_cnt + 4;
     unsigned char *s_pairs = reinterpret_cast<unsigned char *>(s_queue + SYNC_TPB);
 
     const uint32_t S = im.sub_bits, G = im.lane_subs, SQ = MJ_SEQ_LANES * G;
     load_tables(b, im, s_pairs, true);
-    if (threadIdx.x < SYNC_WAVES) {
+    if (threadIdx.x < MJ_WG_SEQS) {
         SeqGeo sg = {0, 0, 0, 0, 0, 0, {0, 0}};
         const uint32_t seq = seq0 + threadIdx.x;
         if (seq < n_seq) {
@@ -256,22 +267,24 @@ __global__ __launch_bounds__(SYNC_TPB, 8) void mj_k_entropy_sync(MjDeviceBatch b
     /* cold pass: the lane's subsequences back to back from a cold state at its first
      * (exact for the first lane of an interval), one record after each */
     {
-        const SeqGeo g = s_geo[wave];
-        const uint32_t u0 = lane * G;
+        const uint32_t sw = wave * SYNC_SPW + lane / SYNC_SEQ_LANES;      /* the lane's sequence within the workgroup */
+        const uint32_t GC = G * SYNC_SPW;                                  /* subsequences per lane in this pass */
+        const SeqGeo g = s_geo[sw];
+        const uint32_t u0 = (lane % SYNC_SEQ_LANES) * GC;
         bool more = false;
         uint32_t task = 0;
         if (u0 < g.n) {
             const uint32_t j0 = g.first + u0;
             MjLane L;
             mj_lane_init(cx, L, g.b0 + j0 * S, 0, 0);
-            for (uint32_t q = 0; q < G; q++) {
+            for (uint32_t q = 0; q < GC; q++) {
                 if (u0 + q < g.n) {
                     const LaneRec r = run_nowrite(cx, L, sub_end(g.b0, g.b1, g.nsub, j0 + q, S));
                     store_rec(b.rec + g.rec_base + u0 + q, r);
                 }
             }
-            more = (u0 + G < g.n);
-            task = pack_task((L.c << 8) | L.k, L.p - (g.b0 + (j0 + G) * S), wave, u0 + G);
+            more = (u0 + GC < g.n);
+            task = pack_task((L.c << 8) | L.k, L.p - (g.b0 + (j0 + GC) * S), sw, u0 + GC);
         }
         push_task(more, task, s_queue, &s_cnt[0]);
     }
@@ -694,12 +707,24 @@ hipError_t mj_launch_entropy(const MjDeviceBatch &b, hipStream_t s) {
     if (b.n_entropy_wg == 0) return hipSuccess;
 #if defined(MJ_EXPERIMENT)
     static const size_t pad = getenv("MJ_TUNE_LDS_PAD") ? (size_t) atol(getenv("MJ_TUNE_LDS_PAD")) : 0;   /* occupancy experiments */
+    static const int force_spw = getenv("MJ_TUNE_SYNC_SPW") ? atoi(getenv("MJ_TUNE_SYNC_SPW")) : 0;
 #else
     const size_t pad = 0;
+    const int force_spw = 0;
 #endif
-    const size_t lds = table_lds(b, 0) + SYNC_WAVES * sizeof(SeqGeo) + 4 * sizeof(uint32_t) + SYNC_TPB * sizeof(uint32_t) +
+    uint32_t cus = 0;
+    const hipError_t e = mj_device_cus(&cus);
+    if (e != hipSuccess) return e;
+    /* long lanes once the short ones would put four wavefronts or more on every SIMD */
+    const bool two = force_spw ? force_spw == 2 : b.n_entropy_wg >= 2 * cus;
+    const uint32_t tpb = SYNC_TPB_MAX / (two ? 2 : 1);
+    const size_t lds = table_lds(b, 0) + MJ_WG_SEQS * sizeof(SeqGeo) + 4 * sizeof(uint32_t) + tpb * sizeof(uint32_t) +
                        (size_t) b.max_nac * sizeof(MjHuffRun) + pad;
-    hipLaunchKernelGGL(mj_k_entropy_sync, dim3(b.n_entropy_wg), dim3(SYNC_TPB), lds, s, b);
+    if (two) {
+        hipLaunchKernelGGL(mj_k_entropy_sync<2>, dim3(b.n_entropy_wg), dim3(tpb), lds, s, b);
+    } else {
+        hipLaunchKernelGGL(mj_k_entropy_sync<1>, dim3(b.n_entropy_wg), dim3(tpb), lds, s, b);
+    }
     return hipGetLastError();
 }
 

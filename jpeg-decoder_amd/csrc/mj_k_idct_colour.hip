@@ -716,18 +716,10 @@ __global__ __launch_bounds__(TPB, MJ_IDCT_WAVES) void mj_k_idct_colour(MjDeviceB
 hipError_t mj_launch_idct_colour(const MjDeviceBatch &b, hipStream_t s) {
     if (b.n_idct_tiles == 0) return hipSuccess;
     /* as many workgroups as the chip holds at once (three per compute unit, by their LDS) */
-    static int cus[64];
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
+    uint32_t cus = 0;
+    const hipError_t e = mj_device_cus(&cus);
     if (e != hipSuccess) return e;
-    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    if (cus[dev] == 0) {
-        int n = 0;
-        e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-        if (e != hipSuccess) return e;
-        cus[dev] = n > 0 ? n : 1;
-    }
-    const uint32_t resident = (uint32_t) cus[dev] * MJ_IDCT_WG_PER_CU;
+    const uint32_t resident = cus * MJ_IDCT_WG_PER_CU;
     const uint32_t need = (b.n_idct_tiles + WAVES - 1) / WAVES;
     hipLaunchKernelGGL(mj_k_idct_colour, dim3(need < resident ? need : resident), dim3(TPB), 0, s, b);
     return hipGetLastError();

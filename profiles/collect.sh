@@ -9,9 +9,11 @@ tag=${1:-prof}
 out=gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
-# the profiled command: the default benchmark minus the CPU leg and the forked input generation
-# (the profiler preload does not survive forks)
-B="bench.py --steps 20 --warmup 3 --no-cpu-baseline --gen-workers 1"
+# the profiled command: the benchmark's timed region alone -- no CPU leg, no forked input
+# generation (the profiler preload does not survive forks), no single-image and no
+# pinned-host legs, whose launches of the same kernels on other sizes, or overlapping each
+# other, would be averaged into the per-kernel figures
+B="bench.py --steps 20 --warmup 3 --no-cpu-baseline --gen-workers 1 --no-singles --no-pipeline"
 timeout -k 10 300 python3 -u bench.py --steps 20 --warmup 3 > "$out/bench.json" 2> "$out/bench.err" &&
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o run -- python3 $B > "$out/stats.log" 2>&1 &&
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -o run -- python3 $B > "$out/pmc_fetch.log" 2>&1 &&
