@@ -59,6 +59,10 @@ constexpr int TPB = WAVES * 64;
  * fill the chip is bound by the time a lane takes and keeps the short lanes.  The records
  * are per subsequence, so the two passes need not agree on the lanes. */
 constexpr int SYNC_TPB_MAX = MJ_WG_SEQS * 64;
+#ifndef MJ_SOLO_MAX
+#define MJ_SOLO_MAX 8
+#endif
+constexpr uint32_t SOLO_MAX = MJ_SOLO_MAX;    /* that many decoders or fewer: one wavefront each at a time */
 
 struct Geo {          /* wave-uniform geometry of one interval */
     uint32_t b0, b1;  /* bit range in the compacted stream */
@@ -156,6 +160,134 @@ __device__ __forceinline__ LaneRec decode_nowrite(const MjScanCtx &cx, uint32_t 
     return run_nowrite(cx, L, end);
 }
 
+/* One decoder, the whole wavefront: what decode_nowrite returns, for a wave-uniform state.
+ * A wavefront issues one instruction at a time however few of its lanes take part, and a
+ * step of the lane-parallel decoder is a hundred instructions.  Here lane l looks up the
+ * code that would start at bit l of a 64-bit window, all lanes at once, and packs where the
+ * symbol after it starts and how far it moves the zigzag index into one word; the decoder
+ * proper is a walk over those words in scalar registers, six instructions per AC symbol.
+ * Symbols start in the first 32 bits of a window, so the next one starts inside its 64; the
+ * lanes past the span answer "stop".  The words are made again when the window moves on and
+ * when the block slot brings other tables.  Symbols are taken one at a time: the symbol runs
+ * of the lane-parallel decoder are defined as what that many single steps do. */
+__device__ __forceinline__ uint32_t uni(uint32_t v) {
+    return __builtin_amdgcn_readfirstlane(v);
+}
+__device__ __forceinline__ uint32_t lane_of(uint32_t v, uint32_t l) {      /* v of lane l (wave-uniform l) */
+    return (uint32_t) __builtin_amdgcn_readlane((int) v, (int) l);
+}
+
+constexpr uint32_t SOLO_STOP = 127u;   /* zigzag step of a word that is not a symbol: past the span, or a long code */
+
+/* lane l's word for lookup entry e: bits 0-6 where the next symbol starts, 8-14 the zigzag
+ * step, 16-20 the code length, 21-24 the number of value bits */
+__device__ __forceinline__ uint32_t solo_word(uint32_t e, uint32_t l, uint32_t lim) {
+    const uint32_t len = MJ_E_LEN(e), size = (e >> 7) & 15u;
+    const uint32_t w = (l + len + size) | ((e & 127u) << 8) | (len << 16) | (size << 21);
+    return (len == 0 || l >= lim) ? (l | (SOLO_STOP << 8)) : w;
+}
+
+__device__ __forceinline__ LaneRec solo_nowrite(const MjScanCtx &cx, uint32_t p_in, uint32_t kc_in, uint32_t end_in, uint32_t lane) {
+    uint32_t p = uni(p_in);
+    const uint32_t kc = uni(kc_in), end = uni(end_in);
+    if (p >= end) {
+        const LaneRec r = {p, kc, 0, 0, 0, 0, 0};
+        return r;
+    }
+    /* the scan's description in scalar registers, so that the walk below stays in them */
+    MjScanCtx sx = cx;
+    sx.slotw0 = uni(cx.slotw0);
+    sx.slotw1 = uni(cx.slotw1);
+    sx.slotw2 = uni(cx.slotw2);
+    const uint32_t bpm = uni(cx.bpm);
+    uint32_t k = kc & 0xFFu, c = kc >> 8;
+    uint32_t slot = mj_slot_of(sx, c);
+    uint32_t nb = 0, d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+    /* the span's stream words in one register, a word per lane: one memory access per 64 words */
+    const uint32_t wlast = ((end - 1u) >> 5) + 2u;             /* the third word of the last window */
+    uint32_t wi0 = p >> 5;
+    uint32_t V = mj_be32((wi0 + lane <= wlast) ? cx.stream[wi0 + lane] : 0u);
+    const uint32_t sh = lane & 31u;
+    const bool up = lane >= 32u;
+    for (;;) {
+        /* the window starts at the word p is in; W: the 32 stream bits from bit `lane` of the window on */
+        uint32_t j = (p >> 5) - wi0;
+        if (j + 2u > 63u) {
+            wi0 = p >> 5;
+            V = mj_be32((wi0 + lane <= wlast) ? cx.stream[wi0 + lane] : 0u);
+            j = 0;
+        }
+        const uint32_t w0 = lane_of(V, j), w1 = lane_of(V, j + 1), w2 = lane_of(V, j + 2);
+        const uint32_t a = up ? w1 : w0, bb = up ? w2 : w1;
+        const uint32_t W = (uint32_t) ((((((uint64_t) a) << 32) | bb) << sh) >> 32);
+        const uint32_t idx2 = (W >> (32 - MJ_LUT_BITS)) << 1;
+        const uint32_t base = p & ~31u;
+        const uint32_t lim = min(32u, end - base);             /* a symbol is decoded when it starts before this */
+        uint32_t o = p - base;                                 /* 0 .. 31, < lim */
+        uint32_t Edc = 0, Eac = 0, Ndc = 0, Nac = 0, have = 0xFFFFFFFFu;
+        for (;;) {
+            if (have != (slot >> 2)) {                         /* the slot's two tables */
+                Edc = *reinterpret_cast<const uint16_t *>(cx.tabs + mj_slot_tdc(slot) + idx2);
+                Eac = *reinterpret_cast<const uint16_t *>(cx.tabs + mj_slot_tac(slot) + idx2);
+                Ndc = solo_word(Edc, lane, lim);
+                Nac = solo_word(Eac, lane, lim);
+                have = slot >> 2;
+            }
+            if (k == 0) {
+                /* the DC symbol: the difference is `size` bits after the code, then EXTEND (decode.c:684-686) */
+                uint32_t x = lane_of(Ndc, o);
+                if (((x >> 8) & 127u) == SOLO_STOP) {          /* o < lim here: a long code */
+                    const uint32_t e = uni(mj_long_code_at(cx, mj_slot_tdc(slot), lane_of(W, o), 0, lane_of(Edc, o)));
+                    x = solo_word(e, o, lim);
+                }
+                const uint32_t len = (x >> 16) & 31u, size = (x >> 21) & 15u;
+                const uint32_t v = size ? lane_of(W, o + len) >> (32u - size) : 0u;
+                const uint32_t full = 1u << size;
+                const uint32_t val = (v < (full >> 1)) ? v + 1u - full : v;
+                const uint32_t comp = slot & 3u;
+                d0 += (comp == 0) ? val : 0u;
+                d1 += (comp == 1) ? val : 0u;
+                d2 += (comp == 2) ? val : 0u;
+                d3 += (comp == 3) ? val : 0u;
+                o = x & 127u;
+                k = 1;
+            }
+            /* AC symbols up to the end of the block, of the span, or a long code */
+            uint32_t x = 0;
+            while (k < 64u) {
+                x = lane_of(Nac, o);
+                k += (x >> 8) & 127u;
+                o = x & 127u;
+            }
+            if (((x >> 8) & 127u) == SOLO_STOP) {
+                k -= SOLO_STOP;                                /* not a symbol: o did not move */
+                if (o >= lim) break;
+                const uint32_t e = uni(mj_long_code_at(cx, mj_slot_tac(slot), lane_of(W, o), 1, lane_of(Eac, o)));
+                o += MJ_E_LEN(e) + ((e >> 7) & 15u);
+                k += e & 127u;
+            }
+            if (k >= 64u) {
+                k = 0;
+                c = (c + 1 == bpm) ? 0 : c + 1;
+                slot = mj_slot_of(sx, c);
+                nb++;
+            }
+            if (o >= lim) break;
+        }
+        p = base + o;
+        if (p >= end) break;
+    }
+    LaneRec r;
+    r.p = p;
+    r.kc = (c << 8) | k;
+    r.nb = nb;
+    r.d0 = (int32_t) (d0 & 0xFFFFu);       /* modulo 2^16, like MjAccPk::sum */
+    r.d1 = (int32_t) (d1 & 0xFFFFu);
+    r.d2 = (int32_t) (d2 & 0xFFFFu);
+    r.d3 = (int32_t) (d3 & 0xFFFFu);
+    return r;
+}
+
 __device__ __forceinline__ void store_rec(MjSubRec *dst, const LaneRec &r) {
     MjSubRec o;
     o.exit.p = r.p;
@@ -225,20 +357,21 @@ __device__ __forceinline__ void push_task(bool have, uint32_t task, uint32_t *qu
 }
 
 template <int SYNC_SPW>
-__global__ __launch_bounds__(MJ_WG_SEQS * 64 / SYNC_SPW, SYNC_SPW == 2 ? 5 : 8) void mj_k_entropy_sync(MjDeviceBatch b) {
+__global__ __launch_bounds__(MJ_WG_SEQS * 64 / SYNC_SPW, SYNC_SPW == 2 ? 5 : 4) void mj_k_entropy_sync(MjDeviceBatch b) {
     constexpr int SYNC_SEQ_LANES = MJ_SEQ_LANES / SYNC_SPW;
     constexpr int SYNC_TPB = MJ_WG_SEQS * 64 / SYNC_SPW;
+    constexpr uint32_t SYNC_WAVES = SYNC_TPB / 64;
     const uint32_t ii = b.wg_img[blockIdx.x];
     const MjImageDev &im = b.img[ii];
     const uint32_t n_seq = b.dyn[ii].n_seq;
     const uint32_t seq0 = (blockIdx.x - im.wg_first) * MJ_WG_SEQS;
     if (seq0 >= n_seq) return;
 
-    /* dynamic LDS: [tables][sequence geometry][3 queue counters][queue][symbol-run tables] */
+    /* dynamic LDS: [tables][sequence geometry][3 queue counters][two queues][symbol-run tables] */
     SeqGeo *s_geo = reinterpret_cast<SeqGeo *>(lds_after_dc(b, 0));
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_geo + MJ_WG_SEQS);
     uint32_t *s_queue = s_cnt + 4;
-    unsigned char *s_pairs = reinterpret_cast<unsigned char *>(s_queue + SYNC_TPB);
+    unsigned char *s_pairs = reinterpret_cast<unsigned char *>(s_queue + 2 * SYNC_TPB);
 
     const uint32_t S = im.sub_bits, G = im.lane_subs, SQ = MJ_SEQ_LANES * G;
     load_tables(b, im, s_pairs, true);
@@ -263,6 +396,9 @@ __global__ __launch_bounds__(MJ_WG_SEQS * 64 / SYNC_SPW, SYNC_SPW == 2 ? 5 : 8) 
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
     const MjScanCtx cx = make_ctx(b, im, s_pairs, true);
+#if defined(MJ_SYNC_TRACE)
+    const unsigned long long t_begin = wall_clock64();
+#endif
 
     /* cold pass: the lane's subsequences back to back from a cold state at its first
      * (exact for the first lane of an interval), one record after each */
@@ -292,27 +428,54 @@ __global__ __launch_bounds__(MJ_WG_SEQS * 64 / SYNC_SPW, SYNC_SPW == 2 ? 5 : 8) 
 
     /* rounds: every queued decoder decodes one more subsequence, replaces its record and
      * goes on while the state it reached differs from the one recorded there before */
+#if defined(MJ_SYNC_TRACE)
+    /* timing experiment: 100 MHz ticks of the cold pass and of the rounds by how many decoders they had
+     * (slots 0 and 3 of the statistics also count in the scan kernels and are left alone) */
+    unsigned long long t_mark = wall_clock64(), t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    t_acc[1] = t_mark - t_begin;
+#endif
     uint32_t rounds = 0, tasks = 0;
     const uint32_t max_rounds = (MJ_DBG(b) >> 8) & 0xFFu;
     uint32_t ci = 0;                         /* counter of this round; next is ci + 1, the one to clear ci + 2 (mod 3) */
     for (;;) {
         const uint32_t total = s_cnt[ci];
         if (total == 0 || (MJ_DBG(b) & 2u) || (max_rounds && rounds >= max_rounds)) break;
-        /* the number of decoders left never grows, so a wavefront that has none now will
-         * get none later: it leaves, and its slot goes to a workgroup still waiting to
-         * start (a barrier only counts the wavefronts that are still there) */
-        if (wave != 0 && wave * 64 >= total) return;
+        /* The number of decoders left never grows.  The last SOLO_MAX get a whole wavefront
+         * each at a time (solo_nowrite), dealt out over the wavefronts of the workgroup;
+         * before that they are lanes of as few wavefronts as hold them.  Wavefront w has
+         * nothing more to do once no more than w decoders are left and leaves (a barrier
+         * only counts the wavefronts that are still there).  Decoders are taken from one
+         * queue and put back into the other, so a round needs one barrier, at its end. */
+        const bool solo = total <= SOLO_MAX;
+        if (total <= wave) return;
         const uint32_t cn = (ci == 2) ? 0 : ci + 1, cz = (cn == 2) ? 0 : cn + 1;
-        if (threadIdx.x == 0) s_cnt[cz] = 0;
+        if (threadIdx.x == 0) s_cnt[cz] = 0;        /* last read a round ago, next added to a round from now */
+        const uint32_t *q_from = s_queue + (rounds & 1u) * SYNC_TPB;
+        uint32_t *q_to = s_queue + ((rounds + 1u) & 1u) * SYNC_TPB;
         rounds++;
         tasks += total;
-        /* one queue: everybody takes its decoder out before anybody puts one back */
-        const uint32_t tk = (threadIdx.x < total) ? s_queue[threadIdx.x] : 0u;
-        __syncthreads();
-        if (wave * 64 < total) {
+        if (solo) {
+            for (uint32_t t = wave; t < total; t += SYNC_WAVES) {
+                const uint32_t tw = uni(q_from[t]);
+                const uint32_t sw = (tw >> 15) & 7u, u = tw >> 18;
+                const uint32_t kc = (tw & 63u) | (((tw >> 6) & 15u) << 8);
+                const SeqGeo g = s_geo[sw];
+                MjSubRec *dst = b.rec + g.rec_base + u;
+                const MjState old = dst->exit;
+                const uint32_t start = g.b0 + (g.first + u) * S;
+                const LaneRec r = solo_nowrite(cx, start + ((tw >> 10) & 31u), kc, sub_end(g.b0, g.b1, g.nsub, g.first + u, S), lane);
+                if (lane == 0) {
+                    store_rec(dst, r);
+                    if (!(r.p == old.p && r.kc == old.kc) && (u + 1 < g.n)) {
+                        q_to[atomicAdd(&s_cnt[cn], 1u)] = pack_task(r.kc, r.p - (start + S), sw, u + 1);
+                    }
+                }
+            }
+        } else if (wave * 64 < total) {
             bool more = false;
             uint32_t task = 0;
             if (threadIdx.x < total) {
+                const uint32_t tk = q_from[threadIdx.x];
                 const uint32_t sw = (tk >> 15) & 7u, u = tk >> 18;
                 const uint32_t kc = (tk & 63u) | (((tk >> 6) & 15u) << 8);
                 const SeqGeo g = s_geo[sw];
@@ -324,11 +487,30 @@ __global__ __launch_bounds__(MJ_WG_SEQS * 64 / SYNC_SPW, SYNC_SPW == 2 ? 5 : 8) 
                 more = !(r.p == old.p && r.kc == old.kc) && (u + 1 < g.n);
                 task = pack_task(r.kc, r.p - (start + S), sw, u + 1);
             }
-            push_task(more, task, s_queue, &s_cnt[cn]);
+            push_task(more, task, q_to, &s_cnt[cn]);
         }
         __syncthreads();
         ci = cn;
+#if defined(MJ_SYNC_TRACE)
+        {
+            const unsigned long long now = wall_clock64();
+            const int bk = total > 64 ? -1 : (total > 8 ? 4 : 6);
+            if (bk > 0) {
+                t_acc[bk] += now - t_mark;
+                t_acc[bk + 1] += 1;
+            }
+            t_mark = now;
+        }
+#endif
     }
+#if defined(MJ_SYNC_TRACE)
+    if (threadIdx.x == 0) {
+        atomicAdd(&b.stats[1], t_acc[1]);
+        atomicMax(&b.stats[2], wall_clock64() - t_begin);      /* the longest-lived workgroup */
+        for (int i = 4; i < 8; i++) atomicAdd(&b.stats[i], t_acc[i]);
+    }
+    return;
+#endif
     if (threadIdx.x == 0) {
         atomicAdd(&b.stats[MJ_ST_ROUNDS], (unsigned long long) rounds);
         atomicMax(&b.stats[MJ_ST_MAXROUNDS], (unsigned long long) rounds);
@@ -341,39 +523,42 @@ __global__ __launch_bounds__(MJ_WG_SEQS * 64 / SYNC_SPW, SYNC_SPW == 2 ? 5 : 8) 
 /* kernel 2a: the first cross-sequence pass, spread over the whole chip      */
 /* ------------------------------------------------------------------------ */
 /* Every sequence that is not the first of its interval is entered by the decoder that
- * left the sequence before it: that decoder goes on here, one lane per such boundary and
- * eight boundaries per workgroup, so that the (serial, lone-lane) decodes of all the
- * boundaries of a long scan run on as many CUs as there are, not on the one CU of the
- * interval's workgroup in mj_k_entropy_fix.  That kernel then finds the entry states it
- * would have used already recorded in seq_seen, repeats only what changed since, and
- * checks convergence as before. */
-__global__ __launch_bounds__(64) void mj_k_entropy_fix_first(MjDeviceBatch b) {
+ * left the sequence before it: that decoder goes on here, one wavefront per such boundary
+ * (solo_nowrite: a lone decoder is several times faster as a wavefront than as a lane) and
+ * eight boundaries per workgroup, so that the serial decodes of all the boundaries of a
+ * long scan run on as many CUs as there are, not on the one CU of the interval's workgroup
+ * in mj_k_entropy_fix.  That kernel then finds the entry states it would have used already
+ * recorded in seq_seen, repeats only what changed since, and checks convergence as before. */
+__global__ __launch_bounds__(MJ_WG_SEQS * 64) void mj_k_entropy_fix_first(MjDeviceBatch b) {
     const uint32_t ii = b.wg_img[blockIdx.x];
     const MjImageDev &im = b.img[ii];
     const uint32_t n_seq = b.dyn[ii].n_seq;
-    const uint32_t sq = (blockIdx.x - im.wg_first) * MJ_WG_SEQS + threadIdx.x;     /* sequence of the image */
-    const bool boundary = threadIdx.x < MJ_WG_SEQS && sq < n_seq && b.seq_sub[im.seq_off + sq] != 0;
-    if (!__any(boundary)) return;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    const uint32_t sq0 = (blockIdx.x - im.wg_first) * MJ_WG_SEQS;           /* first sequence (of the image) of the workgroup */
+    /* lane t of every wavefront looks at sequence t, so all wavefronts decide alike whether to stay */
+    const bool some = lane < MJ_WG_SEQS && sq0 + lane < n_seq && b.seq_sub[im.seq_off + sq0 + lane] != 0;
+    if (!__any(some)) return;
     unsigned char *s_pairs = lds_after_dc(b, 0);
     load_tables(b, im, s_pairs, true);
     __syncthreads();
-    if (!boundary) return;
+    const uint32_t sq = sq0 + wave;
+    if (sq >= n_seq || b.seq_sub[im.seq_off + sq] == 0) return;
     const MjScanCtx cx = make_ctx(b, im, s_pairs, true);
     const uint32_t S = im.sub_bits, SQ = MJ_SEQ_LANES * im.lane_subs;
     const uint32_t iv = b.seq_ivl[im.seq_off + sq], first = b.seq_sub[im.seq_off + sq];
     const Geo g = interval_geo(b.ivl_start + im.ivl_off, iv, S, SQ);
     MjSubRec *rec = b.rec + im.rec_off + (uint64_t) sq * SQ;       /* this sequence's records; the one before them is the entry */
     const MjState e = rec[-1].exit;
-    b.seq_seen[im.seq_off + sq] = e;
-    uint32_t p = e.p, kc = e.kc;
+    if (lane == 0) b.seq_seen[im.seq_off + sq] = e;
+    uint32_t p = uni(e.p), kc = uni(e.kc);
     const uint32_t n = min(g.nsub - first, (uint32_t) SQ);
     for (uint32_t l = 0; l < n; l++) {
-        const LaneRec o = decode_nowrite(cx, p, kc, sub_end(g.b0, g.b1, g.nsub, first + l, S));
         const MjState old = rec[l].exit;
-        store_rec(rec + l, o);
+        const LaneRec o = solo_nowrite(cx, p, kc, sub_end(g.b0, g.b1, g.nsub, first + l, S), lane);
+        if (lane == 0) store_rec(rec + l, o);
         p = o.p;
         kc = o.kc;
-        if (old.p == o.p && old.kc == o.kc) break;
+        if (uni(old.p) == o.p && uni(old.kc) == o.kc) break;
     }
 }
 
@@ -718,7 +903,7 @@ hipError_t mj_launch_entropy(const MjDeviceBatch &b, hipStream_t s) {
     /* long lanes once the short ones would put four wavefronts or more on every SIMD */
     const bool two = force_spw ? force_spw == 2 : b.n_entropy_wg >= 2 * cus;
     const uint32_t tpb = SYNC_TPB_MAX / (two ? 2 : 1);
-    const size_t lds = table_lds(b, 0) + MJ_WG_SEQS * sizeof(SeqGeo) + 4 * sizeof(uint32_t) + tpb * sizeof(uint32_t) +
+    const size_t lds = table_lds(b, 0) + MJ_WG_SEQS * sizeof(SeqGeo) + 4 * sizeof(uint32_t) + 2 * tpb * sizeof(uint32_t) +
                        (size_t) b.max_nac * sizeof(MjHuffRun) + pad;
     if (two) {
         hipLaunchKernelGGL(mj_k_entropy_sync<2>, dim3(b.n_entropy_wg), dim3(tpb), lds, s, b);
@@ -730,7 +915,7 @@ hipError_t mj_launch_entropy(const MjDeviceBatch &b, hipStream_t s) {
 
 hipError_t mj_launch_entropy_fix(const MjDeviceBatch &b, hipStream_t s) {
     if (b.n_multi_cap == 0 || b.n_entropy_wg == 0) return hipSuccess;
-    hipLaunchKernelGGL(mj_k_entropy_fix_first, dim3(b.n_entropy_wg), dim3(64), table_lds(b, 0) + (size_t) b.max_nac * sizeof(MjHuffRun), s, b);
+    hipLaunchKernelGGL(mj_k_entropy_fix_first, dim3(b.n_entropy_wg), dim3(MJ_WG_SEQS * 64), table_lds(b, 0) + (size_t) b.max_nac * sizeof(MjHuffRun), s, b);
     hipLaunchKernelGGL(mj_k_entropy_fix, dim3(b.n_multi_cap), dim3(FIX_TPB),
                        table_lds(b, 0) + (size_t) b.max_nac * sizeof(MjHuffRun), s, b);
     return hipGetLastError();
