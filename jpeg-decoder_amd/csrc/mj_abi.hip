@@ -280,6 +280,15 @@ int prepare(const uint8_t *const *bufs, const size_t *lens, int n, MjPrep &pp, c
         pp.img[i].ent = bufs[i] + P.ent_pos;
         mj_parsed_free(&P);
     }
+    /* the cut of every image once more, now that the size of the batch is known */
+    uint32_t cus = 0;
+    if (mj_device_cus(&cus) != hipSuccess) return set_err("%s: cannot query the device", who);
+    uint64_t batch_bits = 0;
+    for (int i = 0; i < n; i++) batch_bits += (uint64_t) pp.img[i].im.raw_len * 8;
+    for (int i = 0; i < n; i++) {
+        MjImageDev &im = pp.img[i].im;
+        mj_choose_split(im.raw_len, im.n_ivl, batch_bits, cus * 4u * MJ_SEQ_LANES, &im.sub_bits, &im.lane_subs);
+    }
     return 0;
 }
 
