@@ -604,20 +604,21 @@ __global__ __launch_bounds__(FIX_TPB) void mj_k_entropy_fix(MjDeviceBatch b) {
         __syncthreads();
         if (!s_changed) break;
         iters++;
-        for (uint32_t q = 1 + threadIdx.x; q < g.nseq; q += FIX_TPB) {
+        /* one wavefront per boundary that has to be decoded again (solo_nowrite) */
+        for (uint32_t q = 1 + (threadIdx.x >> 6); q < g.nseq; q += FIX_TPB / 64) {
             if (!b.seq_flag[seq_first + q]) continue;
             const MjState e = b.seq_seen[seq_first + q];
-            uint32_t p = e.p, kc = e.kc;
+            uint32_t p = uni(e.p), kc = uni(e.kc);
             const uint32_t first = q * SQ;
             const uint32_t n = min(g.nsub - first, (uint32_t) SQ);
             for (uint32_t l = 0; l < n; l++) {
-                const LaneRec o = decode_nowrite(cx, p, kc, sub_end(g.b0, g.b1, g.nsub, first + l, S));
                 MjSubRec *dst = rec + (uint64_t) first + l;
                 const MjState old = dst->exit;
-                store_rec(dst, o);
+                const LaneRec o = solo_nowrite(cx, p, kc, sub_end(g.b0, g.b1, g.nsub, first + l, S), threadIdx.x & 63u);
+                if ((threadIdx.x & 63u) == 0) store_rec(dst, o);
                 p = o.p;
                 kc = o.kc;
-                if (old.p == o.p && old.kc == o.kc) break;
+                if (uni(old.p) == o.p && uni(old.kc) == o.kc) break;
             }
         }
         __syncthreads();
