@@ -132,6 +132,31 @@ def test_green_that_wraps_to_zero_like_the_reference(ctx, oracle, sampling, rgba
     b.close()
 
 
+@pytest.mark.parametrize("flags", [0, binding.MJ_ENTROPY_SERIAL])
+def test_tables_that_need_the_canonical_walk(ctx, oracle, flags):
+    """Files re-coded with AC tables whose frequent symbols have 11-bit codes over 76 ten-bit
+    prefixes (tests/huffcraft.py): most symbols are found by the canonical ranges
+    (decode.c:674-681), in the lane-parallel passes, the wavefront-wide lone decoder, the
+    cross-sequence passes (the scans have no restart markers) and the writing pass.  One
+    batch of a 640 x 480 4:2:0, a grey and a 4:4:4 file."""
+    import huffcraft
+    files, want = [], []
+    for w, h, sampling, pattern, grey in ((640, 480, "4:2:0", [0, 0, 0, 0, 1, 2], False), (320, 200, "4:4:4", [0], True),
+                                          (200, 120, "4:4:4", [0, 1, 2], False)):
+        src = J.synth.encode_jpeg(J.synth.synth_image(w, h, seed=w + h, grey=grey), sampling, 90, 0)
+        o = oracle.decode(src)
+        data, tabs = huffcraft.recode(src, o.coefs, pattern)
+        assert all(huffcraft.long_prefixes(t) > 8 for t in tabs.values())
+        files.append(data)
+        want.append(oracle.decode(data))
+        assert np.array_equal(want[-1].coefs, o.coefs)
+    b = ctx.batch(files, binding.MJ_WANT_PLANES | flags)
+    b.decode()
+    for i, o in enumerate(want):
+        _check_image(b, i, o.coefs, o.planes, o.rgb, f"re-coded file {i}")
+    b.close()
+
+
 def test_no_restart_long_scan_cross_sequence(ctx, oracle):
     """A scan without restart markers that spans many sequences: exercises the
     cross-sequence fix-up and the second write kernel."""

@@ -137,3 +137,22 @@ def test_oracle_equals_reference_where_green_wraps(oracle, ref, sampling):
     assert np.array_equal(o.coefs, r.coefs) and np.array_equal(o.rgb, r.rgb)
     hit = wrap_triple_pixels(o.planes, sampling)
     assert hit.sum() >= 64 and set(r.rgb[hit][:, 1].tolist()) == {0}
+
+
+@pytest.mark.parametrize("sampling,pattern,grey", [("4:2:0", [0, 0, 0, 0, 1, 2], False), ("4:4:4", [0], True), ("4:4:4", [0, 1, 2], False)],
+                         ids=["420", "grey", "444"])
+def test_tables_that_need_the_canonical_walk(oracle, ref, sampling, pattern, grey):
+    """AC tables whose frequent symbols have 11-bit codes over 76 ten-bit prefixes -- more than
+    the kernels keep second-level tables for, so most symbols are found by the canonical
+    ranges (decode.c:674-681): reference, restatement and the emulated kernels agree."""
+    import jpeg_decoder_amd as J
+    import huffcraft
+    src = J.synth.encode_jpeg(J.synth.synth_image(160, 96, seed=5, grey=grey), sampling, 92, 0)
+    o = oracle.decode(src)
+    data, tabs = huffcraft.recode(src, o.coefs, pattern)
+    assert all(huffcraft.long_prefixes(t) > 8 for t in tabs.values())
+    o2, r2 = oracle.decode(data), ref.decode(data)
+    assert np.array_equal(o2.coefs, o.coefs) and np.array_equal(o2.rgb, o.rgb)
+    assert np.array_equal(r2.coefs, o2.coefs) and np.array_equal(r2.rgb, o2.rgb)
+    got, _ = J.Emu().decode_coefs(data, o.coefs.shape[0] + 16, 0, 0)
+    assert np.array_equal(got[:o.coefs.shape[0]], o.coefs)
