@@ -75,14 +75,21 @@ def long_code_ac_table(freq):
     return {4: order[:10], 11: order[10:]}
 
 
+def sixteen_bit_ac_table(freq):
+    """The six rarest symbols get 3 bits, all others 16 bits."""
+    syms = [EOB, ZRL] + [(r << 4) | s for r in range(16) for s in range(1, 11)]
+    order = sorted(syms, key=lambda s: (freq.get(s, 0), s))
+    return {3: order[:6], 16: order[6:]}
+
+
 def long_prefixes(symbols_by_len, lut_bits=10):
     """Distinct lut_bits-bit prefixes among the codes longer than lut_bits."""
     return len({code >> (ln - lut_bits) for code, ln in _canonical(symbols_by_len).values() if ln > lut_bits})
 
 
-def recode(data, coefs, comps_of_mcu, ac_table_of=long_code_ac_table):
+def recode(data, coefs, comps_of_mcu, ac_table_of=long_code_ac_table, dc_tab=None):
     """The file `data` (baseline, one scan, no DRI) with its coefficients `coefs` (n_blocks x 64,
-    zigzag order, decode order) coded again: DC tables with twelve 4-bit codes, AC tables from
+    zigzag order, decode order) coded again: DC tables dc_tab (default: twelve 4-bit codes), AC tables from
     ac_table_of(symbol frequencies).  comps_of_mcu: component index of every block of an MCU,
     e.g. [0, 0, 0, 0, 1, 2].  Table 0 serves component 0, table 1 the others.
     Returns (file, {table id: symbols_by_len of its AC table})."""
@@ -102,7 +109,7 @@ def recode(data, coefs, comps_of_mcu, ac_table_of=long_code_ac_table):
             freq[t][s] = freq[t].get(s, 0) + 1
         blocks.append((t, cat, dbits, ac))
     n_tab = 1 if ncomp == 1 else 2
-    dc_tab = {4: list(range(12))}
+    dc_tab = dc_tab or {4: list(range(12))}
     ac_tabs = {t: ac_table_of(freq[t]) for t in range(n_tab)}
     dc_code = _canonical(dc_tab)
     ac_code = {t: _canonical(ac_tabs[t]) for t in range(n_tab)}

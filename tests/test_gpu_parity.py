@@ -157,6 +157,24 @@ def test_tables_that_need_the_canonical_walk(ctx, oracle, flags):
     b.close()
 
 
+def test_tables_with_long_dc_codes_and_sixteen_bit_ac_codes(ctx, oracle):
+    """DC differences coded with 12-bit codes and nearly all AC symbols with 16-bit codes
+    (tests/huffcraft.py): the second-level lookups of every pass, DC symbols included, on a
+    scan long enough for the cross-sequence passes."""
+    import huffcraft
+    src = J.synth.encode_jpeg(J.synth.synth_image(480, 320, seed=11), "4:2:0", 90, 0)
+    o = oracle.decode(src)
+    data, _ = huffcraft.recode(src, o.coefs, [0, 0, 0, 0, 1, 2], huffcraft.sixteen_bit_ac_table, {2: [0], 12: list(range(1, 12))})
+    want = oracle.decode(data)
+    assert np.array_equal(want.coefs, o.coefs)
+    for flags in (0, binding.MJ_ENTROPY_SERIAL):
+        b = ctx.batch([data, src], binding.MJ_WANT_PLANES | flags)
+        b.decode()
+        _check_image(b, 0, want.coefs, want.planes, want.rgb, "re-coded file")
+        _check_image(b, 1, o.coefs, o.planes, o.rgb, "its source")
+        b.close()
+
+
 def test_no_restart_long_scan_cross_sequence(ctx, oracle):
     """A scan without restart markers that spans many sequences: exercises the
     cross-sequence fix-up and the second write kernel."""

@@ -156,3 +156,18 @@ def test_tables_that_need_the_canonical_walk(oracle, ref, sampling, pattern, gre
     assert np.array_equal(r2.coefs, o2.coefs) and np.array_equal(r2.rgb, o2.rgb)
     got, _ = J.Emu().decode_coefs(data, o.coefs.shape[0] + 16, 0, 0)
     assert np.array_equal(got[:o.coefs.shape[0]], o.coefs)
+
+
+def test_tables_with_long_dc_codes_and_sixteen_bit_ac_codes(oracle, ref):
+    """DC differences coded with 12-bit codes (second-level lookup in the kernels) and nearly
+    all AC symbols with 16-bit codes: reference, restatement and emulated kernels agree."""
+    import jpeg_decoder_amd as J
+    import huffcraft
+    src = J.synth.encode_jpeg(J.synth.synth_image(160, 96, seed=6), "4:2:0", 92, 0)
+    o = oracle.decode(src)
+    data, _ = huffcraft.recode(src, o.coefs, [0, 0, 0, 0, 1, 2], huffcraft.sixteen_bit_ac_table, {2: [0], 12: list(range(1, 12))})
+    o2, r2 = oracle.decode(data), ref.decode(data)
+    assert np.array_equal(o2.coefs, o.coefs) and np.array_equal(o2.rgb, o.rgb)
+    assert np.array_equal(r2.coefs, o2.coefs) and np.array_equal(r2.rgb, o2.rgb)
+    got, _ = J.Emu().decode_coefs(data, o.coefs.shape[0] + 16, 0, 0)
+    assert np.array_equal(got[:o.coefs.shape[0]], o.coefs)
