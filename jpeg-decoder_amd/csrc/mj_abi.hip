@@ -75,7 +75,7 @@ constexpr size_t kStaticMetaBytes = 4u << 20;   /* page-locked mirror of the met
 /* offsets of every device buffer inside its region (all multiples of 256) */
 struct Offsets {
     /* meta */
-    size_t img, sets, tile_img, wg_img, idct_img, meta_bytes;
+    size_t img, sets, tile_img, wg_img, idct_img, comb, meta_bytes;
     /* state */
     size_t dyn, tile_cnt, tile_base, ivl_start, ivl_seq, seq_ivl, seq_sub, seq_entry, seq_seen, seq_flag, multi, multi_count,
         stats, state_bytes;
@@ -117,6 +117,17 @@ struct mj_ctx {
     mj_batch *sbatch = nullptr;
 };
 
+/* A frame coded in one scan per component (T.81 A.2.2): every scan is decoded as a grey image of
+ * its own (a "unit"), and a last kernel combines the three planes into the RGB of the file.
+ * The unit of component 0 sits at the file's own index, the other two after all the files. */
+struct MjMultiScan {
+    uint32_t file;
+    uint32_t unit[3];        /* by component */
+    uint32_t scan_unit[3];   /* in the order of the scans in the file */
+    uint32_t hsf[3], vsf[3];
+    uint32_t X, Y;
+};
+
 struct mj_batch {
     mj_ctx *ctx = nullptr;
     uint32_t flags = 0;
@@ -125,6 +136,9 @@ struct mj_batch {
     std::vector<MjHuffSet> sets;
     std::vector<uint32_t> tile_img, wg_img;
     std::vector<MjIdctImg> idct_img;
+    size_t n_files = 0;                /* img, info, idct_img also hold the extra units of files with several scans */
+    std::vector<MjMultiScan> multi;
+    std::vector<MjCombine> comb;
     Offsets o{};
     uint64_t raw_bytes = 0;
     const uint8_t *span_src = nullptr;   /* non-null: the images' bytes lie close together in page-locked memory and leave as one copy from here */
@@ -168,6 +182,8 @@ struct MjPrepared {
 /* The images of one call and the distinct Huffman sets among them (mostly one: an
  * encoder's default tables).  A set is built for the first image with a given key only. */
 struct MjPrep {
+    size_t n_files = 0;
+    std::vector<MjMultiScan> multi;
     std::vector<MjPrepared> img;
     std::vector<MjHuffSet> sets;
     std::vector<uint8_t> keys;       /* MJ_HUFF_KEY_BYTES per set */
@@ -241,16 +257,16 @@ int find_set(const MjPrep &pp, const uint8_t *key, size_t len) {
     return -1;
 }
 
-/* one image's parsed headers -> descriptor, building its Huffman set unless the call has it */
-int prepare_one(MjPrep &pp, size_t i, const MjParsed &P, size_t len_after_headers_base, const char **why) {
+/* one scan's parsed headers -> descriptor, building its Huffman set unless the call has it */
+int prepare_one(MjPrep &pp, MjPrepared &dst, const MjParsed &P, size_t len_after_headers_base, const char **why) {
     uint8_t key[MJ_HUFF_KEY_BYTES];
     const size_t klen = mj_huff_key(&P, key);
     int si = find_set(pp, key, klen);
     if (si >= 0) {
-        if (mj_flatten_image(&P, len_after_headers_base, &pp.img[i].im, nullptr, why) != 0) return -1;
+        if (mj_flatten_image(&P, len_after_headers_base, &dst.im, nullptr, why) != 0) return -1;
     } else {
         pp.sets.emplace_back();
-        if (mj_flatten_image(&P, len_after_headers_base, &pp.img[i].im, &pp.sets.back(), why) != 0) {
+        if (mj_flatten_image(&P, len_after_headers_base, &dst.im, &pp.sets.back(), why) != 0) {
             pp.sets.pop_back();
             return -1;
         }
@@ -259,13 +275,90 @@ int prepare_one(MjPrep &pp, size_t i, const MjParsed &P, size_t len_after_header
         memcpy(&pp.keys[(size_t) si * MJ_HUFF_KEY_BYTES], key, klen);
         pp.key_len.push_back(klen);
     }
-    pp.img[i].set = (uint32_t) si;
+    dst.set = (uint32_t) si;
+    return 0;
+}
+
+/* A file whose first scan holds one of its three components: the three scans become three
+ * grey units (decode.c:187-201 re-enters the scan loop for every SOS; the reference's own
+ * bookkeeping does not survive that, see DESIGN, so the behaviour here is T.81's). */
+int prepare_scans(MjPrep &pp, size_t i, const uint8_t *buf, size_t len, MjParsed &P, const char **why, bool &freed) {
+    const FrameHeader &fh = P.fh;
+    if (fh.ncs != 3 || fh.precision != 8) {
+        *why = "several scans: only three-component 8-bit frames are supported";
+        return -1;
+    }
+    uint32_t hmax = 0, vmax = 0;
+    for (int c = 0; c < 3; c++) {
+        hmax = fh.cs[c].hsf > hmax ? fh.cs[c].hsf : hmax;
+        vmax = fh.cs[c].vsf > vmax ? fh.cs[c].vsf : vmax;
+    }
+    if (fh.cs[0].hsf != hmax || fh.cs[0].vsf != vmax) {
+        *why = "several scans: the first component must have the largest sampling factors";
+        return -1;
+    }
+    MjMultiScan mm{};
+    mm.file = (uint32_t) i;
+    mm.X = fh.X;
+    mm.Y = fh.Y;
+    MjPrepared part[3];
+    bool seen[3] = {false, false, false};
+    for (int scan = 0; scan < 3; scan++) {
+        if (P.sh.nics != 1) {
+            *why = "several scans: only scans of one component each are supported";
+            return -1;
+        }
+        int ci = -1;
+        for (int c = 0; c < 3; c++) {
+            if (fh.cs[c].id == P.sh.ics[0].sc) ci = c;
+        }
+        if (ci < 0 || seen[ci]) {
+            *why = "several scans: a scan names an unknown component or one already coded";
+            return -1;
+        }
+        seen[ci] = true;
+        if (fh.cs[ci].hsf == 0 || fh.cs[ci].vsf == 0 || hmax % fh.cs[ci].hsf || vmax % fh.cs[ci].vsf) {
+            *why = "sampling factors that do not divide the maximum are not supported";
+            return -1;
+        }
+        mm.hsf[ci] = fh.cs[ci].hsf;
+        mm.vsf[ci] = fh.cs[ci].vsf;
+        /* the scan as a grey file of the component's own size */
+        MjParsed Q = P;                    /* shares the tables' heap data with P, which outlives it */
+        Component one = fh.cs[ci];
+        one.hsf = one.vsf = 1;
+        Q.fh.cs = &one;
+        Q.fh.ncs = 1;
+        Q.fh.X = one.x;
+        Q.fh.Y = one.y;
+        const size_t ent_end = mj_scan_end(buf, len, P.ent_pos);
+        if (prepare_one(pp, part[ci], Q, ent_end, why) != 0) return -1;
+        part[ci].ent = buf + P.ent_pos;
+        mm.scan_unit[scan] = (uint32_t) ci;      /* component for now; unit index below */
+        if (scan < 2) {
+            const int r = mj_parse_next_scan(buf, len, ent_end, &P, why);
+            if (r != 0) {
+                if (r == 1) *why = "several scans: the file ends before every component was coded";
+                freed = (r < 0);                 /* a rejecting parser has freed P */
+                return -1;
+            }
+        }
+    }
+    pp.img[i] = part[0];
+    mm.unit[0] = (uint32_t) i;
+    for (int c = 1; c < 3; c++) {
+        mm.unit[c] = (uint32_t) pp.img.size();
+        pp.img.push_back(part[c]);
+    }
+    for (int scan = 0; scan < 3; scan++) mm.scan_unit[scan] = mm.unit[mm.scan_unit[scan]];
+    pp.multi.push_back(mm);
     return 0;
 }
 
 /* host: headers -> descriptors (decode.c:160-415 marker walk + table flattening) */
 int prepare(const uint8_t *const *bufs, const size_t *lens, int n, MjPrep &pp, const char *who) {
     pp.img.resize(n);
+    pp.n_files = (size_t) n;
     for (int i = 0; i < n; i++) {
         MjParsed P;
         const char *why = "?";
@@ -273,7 +366,16 @@ int prepare(const uint8_t *const *bufs, const size_t *lens, int n, MjPrep &pp, c
         if (mj_parse_headers(bufs[i], lens[i], &P, &why) != 0) {
             return set_err("%s: image %d: %s", who, i, why);   /* the parser freed what it had */
         }
-        if (prepare_one(pp, (size_t) i, P, lens[i], &why) != 0) {
+        if (P.sh.nics == 1 && P.fh.ncs == 3) {
+            bool freed = false;
+            if (prepare_scans(pp, (size_t) i, bufs[i], lens[i], P, &why, freed) != 0) {
+                if (!freed) mj_parsed_free(&P);
+                return set_err("%s: image %d: %s", who, i, why);
+            }
+            mj_parsed_free(&P);
+            continue;
+        }
+        if (prepare_one(pp, pp.img[i], P, lens[i], &why) != 0) {
             mj_parsed_free(&P);
             return set_err("%s: image %d: %s", who, i, why);
         }
@@ -284,10 +386,9 @@ int prepare(const uint8_t *const *bufs, const size_t *lens, int n, MjPrep &pp, c
     uint32_t cus = 0;
     if (mj_device_cus(&cus) != hipSuccess) return set_err("%s: cannot query the device", who);
     uint64_t batch_bits = 0;
-    for (int i = 0; i < n; i++) batch_bits += (uint64_t) pp.img[i].im.raw_len * 8;
-    for (int i = 0; i < n; i++) {
-        MjImageDev &im = pp.img[i].im;
-        mj_choose_split(im.raw_len, im.n_ivl, batch_bits, cus * 4u * MJ_SEQ_LANES, &im.sub_bits, &im.lane_subs);
+    for (const MjPrepared &u : pp.img) batch_bits += (uint64_t) u.im.raw_len * 8;
+    for (MjPrepared &u : pp.img) {
+        mj_choose_split(u.im.raw_len, u.im.n_ivl, batch_bits, cus * 4u * MJ_SEQ_LANES, &u.im.sub_bits, &u.im.lane_subs);
     }
     return 0;
 }
@@ -367,6 +468,9 @@ int layout(mj_batch *b, const MjPrep &pp, uint32_t flags, bool may_span) {
     b->tile_img.clear();
     b->wg_img.clear();
     b->idct_img.assign((size_t) n, MjIdctImg{});
+    b->n_files = pp.n_files;
+    b->multi = pp.multi;
+    b->comb.clear();
 
     uint64_t raw_total = 0, cmp_total = 0, coef_blocks = 0, rgb_total = 0, plane_total = 0;
     uint64_t n_tiles = 0, n_ivl = 0, n_seq = 0, n_rec = 0, n_wg = 0, n_multi = 0, n_idct = 0;
@@ -448,14 +552,56 @@ int layout(mj_batch *b, const MjPrep &pp, uint32_t flags, bool may_span) {
         inf.rgb_offset = (int64_t) im.rgb_off;
     }
 
+    /* frames coded in one scan per component: the file's entry describes the frame, its RGB is
+     * where the unit of component 0 (same size) has its own, and the planes are always kept */
+    uint32_t comb_max_x = 0, comb_max_y = 0;
+    for (const MjMultiScan &mm : b->multi) {
+        MjCombine cb{};
+        mj_image_info &inf = b->info[mm.file];
+        inf.ncs = 3;
+        inf.n_blocks = 0;
+        inf.entropy_bytes = 0;
+        inf.n_intervals = 0;
+        for (int c = 0; c < 3; c++) {
+            const MjImageDev &u = b->img[mm.unit[c]];
+            cb.plane_off[c] = u.comp[0].plane_off;
+            cb.pw[c] = u.comp[0].pw;
+            cb.hsf[c] = mm.hsf[c];
+            cb.vsf[c] = mm.vsf[c];
+            inf.hsf[c] = (int32_t) mm.hsf[c];
+            inf.vsf[c] = (int32_t) mm.vsf[c];
+            inf.plane_w[c] = (int32_t) u.comp[0].pw;
+            inf.plane_h[c] = (int32_t) u.comp[0].ph;
+            inf.n_blocks += (int64_t) u.n_mcu * u.bpm;
+            inf.entropy_bytes += (int64_t) u.raw_len;
+            inf.n_intervals += (int32_t) u.n_ivl;
+        }
+        const MjImageDev &y = b->img[mm.unit[0]];
+        cb.hmax = mm.hsf[0];
+        cb.vmax = mm.vsf[0];
+        cb.X = mm.X;
+        cb.Y = mm.Y;
+        cb.pitch = y.pitch;
+        cb.rgb_off = y.rgb_off;
+        inf.mcus_x = (int32_t) ((mm.X + 8 * cb.hmax - 1) / (8 * cb.hmax));
+        inf.mcus_y = (int32_t) ((mm.Y + 8 * cb.vmax - 1) / (8 * cb.vmax));
+        inf.blocks_per_mcu = 1;            /* every scan codes one block at a time */
+        comb_max_x = mm.X > comb_max_x ? mm.X : comb_max_x;
+        comb_max_y = mm.Y > comb_max_y ? mm.Y : comb_max_y;
+        b->comb.push_back(cb);
+    }
+
     MjDeviceBatch &d = b->d;
     memset(&d, 0, sizeof d);
     d.n_img = (uint32_t) n;
+    d.n_comb = (uint32_t) b->comb.size();
+    d.comb_max_x = comb_max_x;
+    d.comb_max_y = comb_max_y;
     d.n_tiles = (uint32_t) n_tiles;
     d.n_entropy_wg = (uint32_t) n_wg;
     d.n_multi_cap = (uint32_t) n_multi;
     d.n_idct_tiles = (uint32_t) n_idct;
-    d.want_planes = (flags & MJ_WANT_PLANES) ? 1u : 0u;
+    d.want_planes = ((flags & MJ_WANT_PLANES) || !b->multi.empty()) ? 1u : 0u;
     d.rgba = (flags & MJ_OUT_RGBA) ? 1u : 0u;
 #if defined(MJ_EXPERIMENT)
     d.dbg = (flags >> 16) & 0xFFFFu;
@@ -480,6 +626,7 @@ int layout(mj_batch *b, const MjPrep &pp, uint32_t flags, bool may_span) {
     o.tile_img = m.take(n_tiles * 4);
     o.wg_img = m.take(n_wg * 4);
     o.idct_img = m.take((uint64_t) n * sizeof(MjIdctImg));
+    o.comb = m.take(b->comb.size() * sizeof(MjCombine));
     o.meta_bytes = m.off;
     o.dyn = st.take((uint64_t) n * sizeof(MjImageDyn));
     o.tile_cnt = st.take(n_tiles * sizeof(MjTileCnt));
@@ -515,6 +662,7 @@ void bind(mj_batch *b, uint8_t *meta, uint8_t *state, uint8_t *work, uint8_t *co
     d.tile_img = reinterpret_cast<const uint32_t *>(meta + o.tile_img);
     d.wg_img = reinterpret_cast<const uint32_t *>(meta + o.wg_img);
     d.idct_img = reinterpret_cast<const MjIdctImg *>(meta + o.idct_img);
+    d.comb = reinterpret_cast<const MjCombine *>(meta + o.comb);
     d.dyn = reinterpret_cast<MjImageDyn *>(state + o.dyn);
     d.tile_cnt = reinterpret_cast<MjTileCnt *>(state + o.tile_cnt);
     d.tile_base = reinterpret_cast<MjTileBase *>(state + o.tile_base);
@@ -603,6 +751,7 @@ int upload(mj_batch *b, const std::vector<MjPrepared> &prep, uint8_t *meta, uint
     memcpy(mh + o.tile_img, b->tile_img.data(), b->tile_img.size() * 4);
     memcpy(mh + o.wg_img, b->wg_img.data(), b->wg_img.size() * 4);
     memcpy(mh + o.idct_img, b->idct_img.data(), n * sizeof(MjIdctImg));
+    if (!b->comb.empty()) memcpy(mh + o.comb, b->comb.data(), b->comb.size() * sizeof(MjCombine));
     HIP_TRY(hipMemcpyAsync(meta, mh, o.meta_bytes, hipMemcpyHostToDevice, s));
     uint8_t *raw = const_cast<uint8_t *>(b->d.raw);
     if (b->span_src) {
@@ -666,6 +815,7 @@ int enqueue_decode(mj_batch *b, hipStream_t s) {
         HIP_TRY(mark(4));
     }
     HIP_TRY(mj_launch_idct_colour(b->d, s));
+    HIP_TRY(mj_launch_combine(b->d, s));
     HIP_TRY(mark(5));
     HIP_TRY(hipEventRecord(b->ev_done, s));
     b->decoded = true;
@@ -897,8 +1047,9 @@ int mj_batch_create_scan(mj_ctx *ctx, const uint8_t *entropy, size_t entropy_len
     P.ent_pos = 0;
     MjPrep prep;
     prep.img.resize(1);
+    prep.n_files = 1;
     const char *why = "?";
-    if (prepare_one(prep, 0, P, entropy_len, &why) != 0) {
+    if (prepare_one(prep, prep.img[0], P, entropy_len, &why) != 0) {
         return set_err("mj_batch_create_scan: %s", why);
     }
     prep.img[0].ent = entropy;
@@ -1009,6 +1160,10 @@ int mj_decode_static(mj_ctx *ctx, const uint8_t *const *bufs, const size_t *lens
     if (batch_wait(b)) return -1;
     MjPrep prep;
     if (prepare(bufs, lens, n, prep, "mj_decode_static")) return -1;
+    if (!prep.multi.empty()) {
+        return set_err("mj_decode_static: image %u is coded in several scans, which need plane memory this entry point has none of",
+                       prep.multi.front().file);
+    }
     if (layout(b, prep, flags, true)) return -1;
     const Offsets &o = b->o;
     const size_t need = o.meta_bytes + o.state_bytes + o.work_bytes;
@@ -1040,27 +1195,42 @@ int mj_decode_static(mj_ctx *ctx, const uint8_t *const *bufs, const size_t *lens
 
 /* ---- results ----------------------------------------------------------------------- */
 
+/* the record of file i if it is coded in one scan per component, else null */
+static const MjMultiScan *multi_of(const mj_batch *b, int i) {
+    for (const MjMultiScan &mm : b->multi) {
+        if (mm.file == (uint32_t) i) return &mm;
+    }
+    return nullptr;
+}
+
 int mj_batch_size(const mj_batch *b) {
-    return b ? (int) b->img.size() : -1;
+    return b ? (int) b->n_files : -1;
 }
 
 int mj_batch_image_info(const mj_batch *b, int i, mj_image_info *info) {
-    if (!b || !info || i < 0 || i >= (int) b->info.size()) return set_err("mj_batch_image_info: bad arguments");
+    if (!b || !info || i < 0 || i >= (int) b->n_files) return set_err("mj_batch_image_info: bad arguments");
     *info = b->info[i];
     return 0;
 }
 
 int mj_batch_status(mj_batch *b, int i, uint32_t *status) {
-    if (!b || !status || i < 0 || i >= (int) b->img.size()) return set_err("mj_batch_status: bad arguments");
+    if (!b || !status || i < 0 || i >= (int) b->n_files) return set_err("mj_batch_status: bad arguments");
     if (mj_batch_sync(b)) return -1;
     MjImageDyn dy;
     HIP_TRY(hipMemcpy(&dy, b->d.dyn + i, sizeof dy, hipMemcpyDeviceToHost));
     *status = dy.status;
+    if (const MjMultiScan *mm = multi_of(b, i)) {        /* any of its scans */
+        for (int c = 1; c < 3; c++) {
+            HIP_TRY(hipMemcpy(&dy, b->d.dyn + mm->unit[c], sizeof dy, hipMemcpyDeviceToHost));
+            *status |= dy.status;
+        }
+    }
     return 0;
 }
 
 int mj_batch_scan_end(mj_batch *b, int i, size_t *offset) {
-    if (!b || !offset || i < 0 || i >= (int) b->img.size()) return set_err("mj_batch_scan_end: bad arguments");
+    if (!b || !offset || i < 0 || i >= (int) b->n_files) return set_err("mj_batch_scan_end: bad arguments");
+    if (multi_of(b, i)) return set_err("mj_batch_scan_end: image %d has several scans", i);
     if (mj_batch_sync(b)) return -1;
     MjImageDyn dy;
     HIP_TRY(hipMemcpy(&dy, b->d.dyn + i, sizeof dy, hipMemcpyDeviceToHost));
@@ -1077,7 +1247,7 @@ void *mj_batch_device_coefs(const mj_batch *b) {
 }
 
 int mj_batch_copy_rgb(mj_batch *b, int i, uint8_t *dst, size_t dst_pitch) {
-    if (!b || !dst || i < 0 || i >= (int) b->img.size()) return set_err("mj_batch_copy_rgb: bad arguments");
+    if (!b || !dst || i < 0 || i >= (int) b->n_files) return set_err("mj_batch_copy_rgb: bad arguments");
     const MjImageDev &im = b->img[i];
     const size_t row = (size_t) (b->d.rgba ? 4 : 3) * im.X;
     if (dst_pitch < row) return set_err("mj_batch_copy_rgb: pitch smaller than a row");
@@ -1094,11 +1264,22 @@ int mj_batch_copy_rgb(mj_batch *b, int i, uint8_t *dst, size_t dst_pitch) {
 }
 
 int mj_batch_copy_coefs(mj_batch *b, int i, int16_t *dst) {
-    if (!b || !dst || i < 0 || i >= (int) b->img.size()) return set_err("mj_batch_copy_coefs: bad arguments");
-    const MjImageDev &im = b->img[i];
+    if (!b || !dst || i < 0 || i >= (int) b->n_files) return set_err("mj_batch_copy_coefs: bad arguments");
     if (mj_batch_sync(b)) return -1;
-    const size_t n_blocks = (size_t) im.n_mcu * im.bpm;
-    HIP_TRY(hipMemcpy(dst, b->d.coefs + im.coef_off * 64, n_blocks * 128, hipMemcpyDeviceToHost));
+    size_t n_blocks = 0;
+    if (const MjMultiScan *mm = multi_of(b, i)) {
+        /* scan after scan, in the order of the file */
+        for (int sc = 0; sc < 3; sc++) {
+            const MjImageDev &u = b->img[mm->scan_unit[sc]];
+            const size_t nb = (size_t) u.n_mcu * u.bpm;
+            HIP_TRY(hipMemcpy(dst + n_blocks * 64, b->d.coefs + u.coef_off * 64, nb * 128, hipMemcpyDeviceToHost));
+            n_blocks += nb;
+        }
+    } else {
+        const MjImageDev &im = b->img[i];
+        n_blocks = (size_t) im.n_mcu * im.bpm;
+        HIP_TRY(hipMemcpy(dst, b->d.coefs + im.coef_off * 64, n_blocks * 128, hipMemcpyDeviceToHost));
+    }
     /* HBM holds the blocks in natural order; the caller gets them in zigzag order, as the
      * reference hands them to dequant_data_unit (quant_table.c:131) */
     static const uint8_t natpos[64] = MJ_NATPOS_INIT;
@@ -1111,9 +1292,14 @@ int mj_batch_copy_coefs(mj_batch *b, int i, int16_t *dst) {
 }
 
 int mj_batch_copy_plane(mj_batch *b, int i, int comp, uint8_t *dst) {
-    if (!b || !dst || i < 0 || i >= (int) b->img.size()) return set_err("mj_batch_copy_plane: bad arguments");
-    const MjImageDev &im = b->img[i];
+    if (!b || !dst || i < 0 || i >= (int) b->n_files) return set_err("mj_batch_copy_plane: bad arguments");
     if (!b->d.want_planes) return set_err("mj_batch_copy_plane: batch was created without MJ_WANT_PLANES");
+    if (const MjMultiScan *mm = multi_of(b, i)) {        /* the plane of the component's own scan */
+        if (comp < 0 || comp >= 3) return set_err("mj_batch_copy_plane: no such component");
+        i = (int) mm->unit[comp];
+        comp = 0;
+    }
+    const MjImageDev &im = b->img[i];
     if (comp < 0 || comp >= (int) im.ncs) return set_err("mj_batch_copy_plane: no such component");
     if (mj_batch_sync(b)) return -1;
     HIP_TRY(hipMemcpy(dst, b->d.planes + im.comp[comp].plane_off, (size_t) im.comp[comp].pw * im.comp[comp].ph,

@@ -141,6 +141,18 @@ typedef struct {
     uint32_t pad_;
 } MjImageDev;
 
+/* A frame coded in one scan per component: where the three planes its scans were decoded into
+ * lie, and where the RGB of the file goes (the last kernel of the decode combines them). */
+typedef struct {
+    uint64_t plane_off[3];   /* byte offsets in the batch plane buffer, by component */
+    uint64_t rgb_off;        /* first byte in the RGB buffer */
+    uint32_t pw[3];          /* plane strides */
+    uint32_t hsf[3], vsf[3]; /* sampling factors of the frame */
+    uint32_t hmax, vmax;
+    uint32_t X, Y, pitch;
+    uint32_t pad_;
+} MjCombine;
+
 /* What the IDCT + colour kernel needs to know about an image, in one 64-byte record that a
  * wavefront reads with a single scalar load. */
 typedef struct {

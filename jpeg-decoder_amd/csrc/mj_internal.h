@@ -61,6 +61,8 @@ struct MjDeviceBatch {
     uint32_t *multi_count;
     const uint32_t *wg_img;  /* [n_entropy_wg] image of each entropy workgroup */
     const MjIdctImg *idct_img; /* [n_img] what the IDCT + colour kernel reads per image */
+    const MjCombine *comb;   /* [n_comb] frames coded in one scan per component */
+    uint32_t n_comb, comb_max_x, comb_max_y;
     int16_t *coefs;
     uint8_t *planes;
     uint8_t *rgb;
@@ -83,6 +85,7 @@ hipError_t mj_launch_entropy_fix(const MjDeviceBatch &b, hipStream_t s);
 hipError_t mj_launch_entropy_write(const MjDeviceBatch &b, hipStream_t s);
 hipError_t mj_launch_entropy_serial(const MjDeviceBatch &b, hipStream_t s);
 hipError_t mj_launch_idct_colour(const MjDeviceBatch &b, hipStream_t s);
+hipError_t mj_launch_combine(const MjDeviceBatch &b, hipStream_t s);
 
 /* Compute units of the current device (asked once per device). */
 static inline hipError_t mj_device_cus(uint32_t *out) {

@@ -711,6 +711,28 @@ __global__ __launch_bounds__(TPB, MJ_IDCT_WAVES) void mj_k_idct_colour(MjDeviceB
 #endif
 }
 
+/* ------------------------------------------------------------------------ */
+/* frames coded in one scan per component                                   */
+/* ------------------------------------------------------------------------ */
+/* Every scan of such a frame has been decoded as a grey image of the component's own size, with
+ * its plane kept; this kernel is the upsample + colour step of the frame (colour_conversion.c:30-83:
+ * nearest neighbour, source index = (uint32)(ratio * i) with ratio = (float) sf / max_sf) from those
+ * planes into the RGB of the file.  One thread per pixel; such files are rare. */
+__global__ __launch_bounds__(256) void mj_k_combine(MjDeviceBatch b) {
+    const MjCombine &cb = b.comb[blockIdx.z];
+    const uint32_t x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= cb.X || y >= cb.Y) return;
+    uint32_t v[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float hr = (float) cb.hsf[c] / (float) cb.hmax, vr = (float) cb.vsf[c] / (float) cb.vmax;
+        const uint32_t sx = (uint32_t) (hr * (float) x), sy = (uint32_t) ((float) y * vr);
+        v[c] = b.planes[cb.plane_off[c] + (uint64_t) sy * cb.pw[c] + sx];
+    }
+    const uint32_t px = mj_ycc_to_rgb(v[0], v[1], v[2], c_chroma.t[v[1]], c_chroma.t[256 + v[2]]);
+    store_px(b.rgb + cb.rgb_off + (uint64_t) y * cb.pitch, x, px, b.rgba != 0);
+}
+
 }  // namespace
 
 hipError_t mj_launch_idct_colour(const MjDeviceBatch &b, hipStream_t s) {
@@ -722,5 +744,11 @@ hipError_t mj_launch_idct_colour(const MjDeviceBatch &b, hipStream_t s) {
     const uint32_t resident = cus * MJ_IDCT_WG_PER_CU;
     const uint32_t need = (b.n_idct_tiles + WAVES - 1) / WAVES;
     hipLaunchKernelGGL(mj_k_idct_colour, dim3(need < resident ? need : resident), dim3(TPB), 0, s, b);
+    return hipGetLastError();
+}
+
+hipError_t mj_launch_combine(const MjDeviceBatch &b, hipStream_t s) {
+    if (b.n_comb == 0) return hipSuccess;
+    hipLaunchKernelGGL(mj_k_combine, dim3((b.comb_max_x + 255) / 256, b.comb_max_y, b.n_comb), dim3(256), 0, s, b);
     return hipGetLastError();
 }

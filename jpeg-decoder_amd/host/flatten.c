@@ -28,10 +28,11 @@ static int fail_free(MjParsed *out, const char **why, const char *msg) {
     return fail(why, msg);
 }
 
-int mj_parse_headers(const uint8_t *buf, size_t len, MjParsed *out, const char **why) {
-    memset(out, 0, sizeof *out);
-    out->fh.process = (Encoding) -1; /* jpeg_decoder.c:54 */
-    Bitstream bs = {(uint8_t *) buf, 0, 0};
+/* The marker walk from offset `from` up to and including the next scan header.  0: a scan
+ * header was read (out->sh, out->ent_pos); 1: the file ended first; -1: rejected.  `resumed`:
+ * the walk continues after a scan of the same frame, which a frame header may not follow. */
+static int walk_to_scan(const uint8_t *buf, size_t len, size_t from, MjParsed *out, const char **why, int resumed) {
+    Bitstream bs = {(uint8_t *) buf + from, 0, 0};
     const uint8_t *end = buf + len;
     while (bs.encoded_data + 1 < end) {
         if (next_byte(&bs) != 0xFF) {
@@ -59,6 +60,9 @@ int mj_parse_headers(const uint8_t *buf, size_t len, MjParsed *out, const char *
         switch (m) {
             case 0xC0: /* SOF0 baseline */
             case 0xC1: /* SOF1 extended sequential, handled like baseline (decode.c:187-201) */
+                if (resumed) {
+                    return fail_free(out, why, "a second frame header");
+                }
                 if (out->have_fh) {
                     free_frame_header(&out->fh);
                 }
@@ -116,7 +120,35 @@ int mj_parse_headers(const uint8_t *buf, size_t len, MjParsed *out, const char *
         bs.encoded_data = seg + seglen;
         bs.offset = 0;
     }
-    return fail_free(out, why, "no scan found");
+    return 1;
+}
+
+int mj_parse_headers(const uint8_t *buf, size_t len, MjParsed *out, const char **why) {
+    memset(out, 0, sizeof *out);
+    out->fh.process = (Encoding) -1; /* jpeg_decoder.c:54 */
+    const int r = walk_to_scan(buf, len, 0, out, why, 0);
+    return r == 1 ? fail_free(out, why, "no scan found") : r;
+}
+
+int mj_parse_next_scan(const uint8_t *buf, size_t len, size_t from, MjParsed *p, const char **why) {
+    return walk_to_scan(buf, len, from, p, why, 1);
+}
+
+size_t mj_scan_end(const uint8_t *buf, size_t len, size_t ent_pos) {
+    size_t i = ent_pos;
+    while (i + 1 < len) {
+        const uint8_t *f = (const uint8_t *) memchr(buf + i, 0xFF, len - 1 - i);
+        if (!f) {
+            break;
+        }
+        i = (size_t) (f - buf);
+        const uint8_t m = buf[i + 1];
+        if (m != 0x00 && m != 0xFF && !(m >= 0xD0 && m <= 0xD7)) {
+            return i;
+        }
+        i++;
+    }
+    return len;
 }
 
 void mj_parsed_free(MjParsed *p) {

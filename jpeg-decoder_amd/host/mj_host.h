@@ -31,6 +31,14 @@ typedef struct {
 int mj_parse_headers(const uint8_t *buf, size_t len, MjParsed *out, const char **why);
 void mj_parsed_free(MjParsed *p);
 
+/* Frames coded in several scans: where the entropy-coded segment that starts at ent_pos ends
+ * (offset of the next marker that is not a stuffed FF00, a fill byte or RSTn; len if none), and
+ * the marker walk continued from there with the tables in force (DHT, DQT and DRI segments
+ * between scans replace them) up to the next scan header.  0: p->sh and p->ent_pos describe
+ * the next scan; 1: no further scan; -1: rejected (p is freed). */
+size_t mj_scan_end(const uint8_t *buf, size_t len, size_t ent_pos);
+int mj_parse_next_scan(const uint8_t *buf, size_t len, size_t from, MjParsed *p, const char **why);
+
 /* huff_table.h:9-14 -> lookup form. */
 void mj_flatten_huff(const HuffTable *ht, int is_ac, MjHuffDev *out, MjHuffWalk *walk, MjHuffRun *pair, MjHuffPair *next);
 

@@ -308,7 +308,10 @@ static void put_dht(BW *w, int tc_th, const uint8_t *bits, const uint8_t *vals) 
  *         2,2 = 4:2:0; 1,2 = 4:4:0; 4,1 = 4:1:1.  Ignored for grey.
  * ri: restart interval in MCUs (0 = no DRI segment, no RST markers).
  * flags: bit 0 = fit the Huffman tables to the image instead of using the Annex K ones;
- *        bit 1 = the three bytes of a pixel are Y, Cb, Cr already (no colour conversion).
+ *        bit 1 = the three bytes of a pixel are Y, Cb, Cr already (no colour conversion);
+ *        bit 2 = one scan per component (non-interleaved, T.81 A.2.2: a scan of one component
+ *                codes its ceil(x/8) x ceil(y/8) blocks in raster order, the restart interval
+ *                counts blocks) instead of one interleaved scan.
  * Returns the number of bytes the stream needs; it is complete only if that is
  * <= cap.  Negative on bad arguments.
  */
@@ -475,6 +478,39 @@ int64_t mjs_encode2(const uint8_t *pix, int W, int H, int ncomp, int hs, int vs,
     }
     if (ri) {
         bw_byte(&w, 0xFF); bw_byte(&w, 0xDD); bw_u16(&w, 4); bw_u16(&w, ri);
+    }
+    if ((flags & 4) && ncomp == 3) {
+        /* three scans of one component each */
+        for (int c = 0; c < 3; c++) {
+            const int hc = c ? 1 : hs, vc = c ? 1 : vs, base = c ? hs * vs + (c - 1) : 0;
+            const int xc = (W * hc + hs - 1) / hs, yc = (H * vc + vs - 1) / vs;     /* samples of the component */
+            const int bw_c = (xc + 7) / 8, bh_c = (yc + 7) / 8;
+            bw_byte(&w, 0xFF); bw_byte(&w, 0xDA); bw_u16(&w, 8); bw_byte(&w, 1);
+            bw_byte(&w, c + 1); bw_byte(&w, c ? 0x11 : 0x00);
+            bw_byte(&w, 0); bw_byte(&w, 63); bw_byte(&w, 0);
+            int pred = 0, rst = 0;
+            int64_t done = 0;
+            for (int by = 0; by < bh_c; by++) {
+                for (int bx = 0; bx < bw_c; bx++, done++) {
+                    if (ri && done && (done % ri) == 0) {
+                        bw_flush(&w);
+                        bw_byte(&w, 0xFF);
+                        bw_byte(&w, 0xD0 + (rst++ & 7));
+                        pred = 0;
+                    }
+                    const int64_t mcu = (int64_t) (by / vc) * mx + bx / hc;
+                    const int16_t *q = Q + (mcu * bpm + base + (by % vc) * hc + bx % hc) * 64;
+                    enc_block(&w, q, &pred, c ? &dcc : &dcl, c ? &acc : &acl, NULL, NULL);
+                }
+            }
+            bw_flush(&w);
+        }
+        bw_byte(&w, 0xFF); bw_byte(&w, 0xD9);
+        free(Q);
+        free(Yp);
+        free(Cb);
+        free(Cr);
+        return (int64_t) w.pos;
     }
     bw_byte(&w, 0xFF); bw_byte(&w, 0xDA); bw_u16(&w, 6 + 2 * ncomp); bw_byte(&w, ncomp);
     bw_byte(&w, 1); bw_byte(&w, 0x00);

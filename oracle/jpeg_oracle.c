@@ -16,6 +16,12 @@
  *   - grey output reads the padded plane with its real stride
  *     (colour_conversion.c:20 strides by the image width).
  *
+ * Files whose frame is coded in several scans of one component each (T.81 A.2.2, B.2.3) are
+ * decoded by orc_run_scans below.  PARITY UNPINNED for that path: the reference re-enters its
+ * scan loop without resetting its MCU counter (decode.c:125, :473, :504) and writes past its
+ * planes, so it has no output to be equal to; the tests pin this path instead against the
+ * interleaved coding of the same coefficients, which the reference does decode.
+ *
  * Build with -ffp-contract=off: the float/double rounding points below are the
  * reference's (gcc -std=c17 -O2 on x86-64, FLT_EVAL_METHOD 0, no FMA contraction).
  */
@@ -562,6 +568,130 @@ static int orc_colour(const OJpeg *j, uint8_t **plane, uint8_t *rgb, int pitch) 
 }
 
 /* ------------------------------------------------------------------------ */
+/* several scans of one component each                                      */
+/* ------------------------------------------------------------------------ */
+/* where the entropy-coded segment that starts at p ends: the next marker that is neither a
+ * stuffed FF00, a fill byte nor RSTn (T.81 B.1.1.5) */
+static const uint8_t *oscan_end(const uint8_t *p, const uint8_t *end) {
+    while (p + 1 < end) {
+        if (p[0] == 0xFF && p[1] != 0x00 && p[1] != 0xFF && !(p[1] >= 0xD0 && p[1] <= 0xD7)) {
+            return p;
+        }
+        p++;
+    }
+    return end;
+}
+
+/* T.81 A.2.2: a scan of one component codes its ceil(x/8) x ceil(y/8) blocks in raster order;
+ * the restart interval counts blocks; tables are those in force at its SOS.  Coefficients come
+ * out scan after scan in coding order, planes are padded to whole blocks, and the colour stage
+ * is the reference's (colour_conversion.c:30-83) on those planes. */
+static int orc_run_scans(const uint8_t *buf, size_t len, int want_tap, int want_rgb, OrcOut *out) {
+    OJpeg *j = (OJpeg *) calloc(1, sizeof(OJpeg));
+    int16_t *coefs = NULL;
+    int64_t nb_total = 0, nb_cap = 0;
+    int seen[4] = {0, 0, 0, 0}, have_sof = 0, rc = -1;
+    size_t pos = 0;
+    if (!j) return -1;
+    while (pos + 1 < len) {
+        if (buf[pos] != 0xFF) {
+            pos++;
+            continue;
+        }
+        int m = buf[pos + 1];
+        pos += 2;
+        if (m == 0xD8 || m == 0x01 || m == 0xFF || (m >= 0xD0 && m <= 0xD7)) {
+            if (m == 0xFF) pos--;
+            continue;
+        }
+        if (m == 0xD9) break;
+        if (pos + 2 > len) goto done;
+        int seglen = be16(buf + pos);
+        if (seglen < 2 || pos + (size_t) seglen > len) goto done;
+        const uint8_t *body = buf + pos + 2;
+        int blen = seglen - 2;
+        if (m == 0xC0 || m == 0xC1) {
+            if (have_sof || parse_sof(j, body, blen) || j->precision != 8 || j->ncs != 3) goto done;
+            have_sof = 1;
+            for (int i = 0; i < 3; i++) {
+                OComp *c = &j->c[i];
+                c->pw = pad_up(c->x, 8);
+                c->ph = pad_up(c->y, 8);
+                out->plane_w[i] = c->pw;
+                out->plane_h[i] = c->ph;
+                out->hsf[i] = c->hsf;
+                out->vsf[i] = c->vsf;
+                out->plane[i] = (uint8_t *) calloc((size_t) c->pw * c->ph + 16, 1);
+            }
+        } else if (m == 0xC4) {
+            if (parse_dht(j, body, blen)) goto done;
+        } else if (m == 0xDB) {
+            if (parse_dqt(j, body, blen)) goto done;
+        } else if (m == 0xDD) {
+            if (blen != 2) goto done;
+            j->ri = be16(body);
+        } else if (m >= 0xC2 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
+            goto done;
+        } else if (m == 0xDA) {
+            if (!have_sof || parse_sos(j, body, blen) || j->nscan != 1) goto done;
+            const int ci = j->scan_comp[0];
+            const OComp *c = &j->c[ci];
+            if (seen[ci]) goto done;
+            seen[ci] = 1;
+            const uint8_t *ent = buf + pos + seglen, *end = oscan_end(ent, buf + len);
+            const int bw = c->pw / 8, bh = c->ph / 8;
+            const int64_t nb = (int64_t) bw * bh;
+            if (nb_total + nb > nb_cap) {
+                nb_cap = (nb_total + nb) * 2;
+                coefs = (int16_t *) realloc(coefs, (size_t) nb_cap * 64 * sizeof(int16_t) + 16);
+            }
+            int16_t *cs = coefs + nb_total * 64;
+            memset(cs, 0, (size_t) nb * 64 * sizeof(int16_t));
+            OBits b = {ent, buf + len, 0};
+            const OHuff *dc = &j->ht[0][c->dc & 3], *ac = &j->ht[1][c->ac & 3];
+            int16_t pred = 0, px[64];
+            for (int64_t k = 0; k < nb; k++) {
+                if (j->ri && k && (k % j->ri) == 0) {
+                    orestart(&b);
+                    pred = 0;
+                }
+                oblock(&b, dc, ac, &pred, cs + k * 64);
+                orc_dequant_idct(cs + k * 64, j->qt[c->qtid & 3], px);
+                const int x0 = 8 * (int) (k % bw), y0 = 8 * (int) (k / bw);
+                for (int r = 0; r < 8; r++) {
+                    for (int q = 0; q < 8; q++) {
+                        out->plane[ci][(size_t) (y0 + r) * c->pw + x0 + q] = (uint8_t) px[8 * r + q];
+                    }
+                }
+            }
+            nb_total += nb;
+            pos = (size_t) (end - buf);
+            continue;
+        }
+        pos += (size_t) seglen;
+    }
+    if (!have_sof || !seen[0] || !seen[1] || !seen[2]) goto done;
+    out->X = j->X;
+    out->Y = j->Y;
+    out->ncs = 3;
+    rc = 0;
+    if (want_rgb) {
+        out->pitch = 3 * j->X;
+        out->rgb = (uint8_t *) calloc((size_t) out->pitch * j->Y + 16, 1);
+        rc = orc_colour(j, out->plane, out->rgb, out->pitch);
+    }
+    if (want_tap) {
+        out->nblocks = nb_total;
+        out->coefs = coefs;
+        coefs = NULL;
+    }
+done:
+    free(coefs);
+    free(j);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------ */
 /* public entry points                                                      */
 /* ------------------------------------------------------------------------ */
 static int orc_run(const uint8_t *buf, size_t len, int want_tap, int want_rgb, OrcOut *out, uint8_t *rgb_reuse) {
@@ -569,6 +699,10 @@ static int orc_run(const uint8_t *buf, size_t len, int want_tap, int want_rgb, O
     if (!j || orc_parse(buf, len, j) != 0) {
         free(j);
         return -1;
+    }
+    if (j->nscan == 1 && j->ncs == 3 && j->precision == 8 && !rgb_reuse) {
+        free(j);
+        return orc_run_scans(buf, len, want_tap, want_rgb, out);   /* one scan per component */
     }
     if (j->nscan != j->ncs || j->precision != 8) {
         free(j);

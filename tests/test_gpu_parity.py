@@ -11,7 +11,8 @@ import pytest
 
 import jpeg_decoder_amd as J
 from jpeg_decoder_amd import binding
-from conftest import PARITY_FIXTURES, load_fixture, wrap_triple_pixels, ycc_neighbourhood_jpeg
+from conftest import (PARITY_FIXTURES, SCANS_PER_COMPONENT_CASES, load_fixture, scans_per_component_pair, wrap_triple_pixels,
+                      ycc_neighbourhood_jpeg)
 
 pytestmark = pytest.mark.gpu
 
@@ -173,6 +174,38 @@ def test_tables_with_long_dc_codes_and_sixteen_bit_ac_codes(ctx, oracle):
         _check_image(b, 0, want.coefs, want.planes, want.rgb, "re-coded file")
         _check_image(b, 1, o.coefs, o.planes, o.rgb, "its source")
         b.close()
+
+
+@pytest.mark.parametrize("flags", [0, binding.MJ_OUT_RGBA, binding.MJ_ENTROPY_SERIAL])
+def test_frames_coded_in_one_scan_per_component(ctx, oracle, flags):
+    """Files with three scans of one component each (T.81 A.2.2), mixed with their interleaved
+    twins in one batch: coefficients (scan after scan), the planes of the components and RGB
+    against the restatement, and RGB against the twin (which the reference decodes).  Parity
+    with the reference itself is unpinned for these files: it has no output for them."""
+    files, want = [], []
+    for case in SCANS_PER_COMPONENT_CASES:
+        multi, inter = scans_per_component_pair(case)
+        files += [multi, inter]
+        want += [oracle.decode(multi), oracle.decode(inter)]
+    big = J.synth.encode_jpeg(J.synth.synth_image(1280, 720, seed=4), "4:2:0", 88, 0, scans_per_component=True)
+    files.append(big)
+    want.append(oracle.decode(big))
+    b = ctx.batch(files, flags)
+    assert len(files) == C.c_int(b.lib.mj_batch_size(b.h)).value
+    b.decode()
+    for i, o in enumerate(want):
+        assert b.status(i) == 0, i
+        assert np.array_equal(b.coefs(i), o.coefs), f"file {i}: coefficients"
+        out = b.rgb(i)
+        assert np.array_equal(out[..., :3], o.rgb), f"file {i}: RGB"
+        if flags & binding.MJ_OUT_RGBA:
+            assert (out[..., 3] == 255).all()
+        if i % 2 == 0:
+            for c, p in enumerate(o.planes):
+                assert np.array_equal(b.plane(i, c), p), f"file {i}: plane {c}"
+            if i + 1 < len(want) and i < 2 * len(SCANS_PER_COMPONENT_CASES):
+                assert np.array_equal(o.rgb, want[i + 1].rgb)
+    b.close()
 
 
 def test_no_restart_long_scan_cross_sequence(ctx, oracle):

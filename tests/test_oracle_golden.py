@@ -61,3 +61,43 @@ def test_integer_red_and_blue_equal_the_float_path(oracle):
     other = (c[::-1]).copy()
     assert np.array_equal(rows(y, other, c)[:, 0].astype(int), red)
     assert np.array_equal(rows(y, c, other)[:, 2].astype(int), blue)
+
+
+def _case_id(c):
+    return f"{c[0]}x{c[1]}_{c[2]}_q{c[3]}_ri{c[4]}" + ("_fitted" if c[5] else "")
+
+
+from conftest import SCANS_PER_COMPONENT_CASES, scans_per_component_pair  # noqa: E402
+
+
+@pytest.mark.parametrize("case", SCANS_PER_COMPONENT_CASES, ids=_case_id)
+def test_one_scan_per_component_equals_the_interleaved_coding(oracle, case):
+    """A frame coded in one scan per component (T.81 A.2.2).  The reference has no output for
+    such files (it keeps counting MCUs across scans, decode.c:125, :473, :504, and writes past
+    its planes), so the restatement is pinned through the interleaved coding of the same
+    quantised coefficients, which the reference does decode: same RGB, same visible samples,
+    and the same coefficient blocks once they are put in the same order."""
+    multi, inter = scans_per_component_pair(case)
+    assert multi.count(b"\xff\xda") == 3
+    m, i = oracle.decode(multi), oracle.decode(inter)
+    assert np.array_equal(m.rgb, i.rgb)
+    w, h = case[0], case[1]
+    hs, vs = m.hsf[0], m.vsf[0]
+    assert np.array_equal(m.planes[0][:h, :w], i.planes[0][:h, :w])
+    cw, ch = -(-w // hs), -(-h // vs)
+    for c in (1, 2):
+        assert np.array_equal(m.planes[c][:ch, :cw], i.planes[c][:ch, :cw])
+    # coefficient blocks: component by component in raster order against MCU by MCU
+    mcus_x = i.planes[0].shape[1] // (8 * hs)
+    bpm = hs * vs + 2
+    at = 0
+    for c in range(3):
+        hc, vc = (hs, vs) if c == 0 else (1, 1)
+        base = 0 if c == 0 else hs * vs + c - 1
+        bw, bh = m.planes[c].shape[1] // 8, m.planes[c].shape[0] // 8
+        for by in range(bh):
+            for bx in range(bw):
+                src = ((by // vc) * mcus_x + bx // hc) * bpm + base + (by % vc) * hc + bx % hc
+                assert np.array_equal(m.coefs[at], i.coefs[src]), (c, bx, by)
+                at += 1
+    assert at == m.coefs.shape[0]
