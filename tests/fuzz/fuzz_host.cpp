@@ -9,12 +9,12 @@
 #include <cstring>
 #include <vector>
 
+#include "mj_host.h"
+
 extern "C" long long mj_emu_decode_coefs(const uint8_t *data, size_t len, int16_t *out, long long cap, uint32_t force,
                                          long long *stats);
-// the drop-in walker (decode_host.c) over stub_abi.c: runs up to the scan, where the stub refuses
-extern "C" int decode_jpeg_buffer(uint8_t *buf, size_t len, void *fh, void **img);
-extern "C" void free_img(void *img);
-extern "C" int32_t free_frame_header(void *fh);
+// decode_jpeg_buffer (mj_host.h -> mi355jpeg_compat.h) is the drop-in walker (decode_host.c) over stub_abi.c:
+// it runs up to the scan, where the stub refuses
 
 // Every input is handed over in an allocation of exactly its size, so that a read one byte
 // past the end lands in a sanitizer red zone (a shrunk std::vector keeps its capacity).
@@ -23,15 +23,32 @@ static long long run_exact(const std::vector<uint8_t> &d, int16_t *out, long lon
     if (!p) abort();
     memcpy(p, d.data(), d.size());
     const long long n = mj_emu_decode_coefs(p, d.size(), out, cap, force, st);
-    alignas(8) unsigned char fh[64];
-    memset(fh, 0, sizeof fh);
-    int32_t minus1 = -1;
-    memcpy(fh, &minus1, 4);
-    void *img = nullptr;
+    {   // the marker walk over every scan of the file, as the batch front end does it for frames coded in several scans
+        MjParsed P;
+        const char *why = "?";
+        if (mj_parse_headers(p, d.size(), &P, &why) == 0) {
+            bool freed = false;
+            for (int k = 0; k < 6; k++) {
+                const size_t e = mj_scan_end(p, d.size(), P.ent_pos);
+                if (e > d.size() || e < P.ent_pos) abort();
+                const int r = mj_parse_next_scan(p, d.size(), e, &P, &why);
+                if (r != 0) {
+                    freed = (r < 0);
+                    break;
+                }
+                if (P.ent_pos > d.size()) abort();
+            }
+            if (!freed) mj_parsed_free(&P);
+        }
+    }
+    FrameHeader fh;
+    memset(&fh, 0, sizeof fh);
+    fh.process = (Encoding) -1;
+    Image *img = nullptr;
     // a file cut before its scan "decodes" to blank planes, as in the reference (decode.c:417-423)
-    if (decode_jpeg_buffer(p, d.size(), fh, &img) == 0) {
+    if (decode_jpeg_buffer(p, d.size(), &fh, &img) == 0) {
         free_img(img);
-        free_frame_header(fh);
+        free_frame_header(&fh);
     }
     free(p);
     return n;

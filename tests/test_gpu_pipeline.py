@@ -98,6 +98,35 @@ def test_pipeline_at_baseline_shapes_equals_one_shot(ctx):
         p.close()
 
 
+@pytest.mark.parametrize("pinned", [False, True])
+def test_pipeline_with_files_of_one_scan_per_component(ctx, oracle, pinned):
+    """Files coded in one scan per component expand into extra units behind the files of the
+    batch: through the pipeline's slots, from pageable and from page-locked memory, between
+    ordinary files; every file against the restatement."""
+    from conftest import SCANS_PER_COMPONENT_CASES, scans_per_component_pair
+    pairs = [scans_per_component_pair(c) for c in SCANS_PER_COMPONENT_CASES[:4]]
+    batches = [[pairs[0][1], pairs[0][0], pairs[1][0]], [pairs[2][0]], [pairs[3][1], pairs[1][1], pairs[3][0], pairs[2][1]]]
+    pipe = ctx.pipe(2, 0)
+    keep, done = [], []
+    for files in batches * 2:
+        src = binding.PinnedFiles(files) if pinned else files
+        keep.append(src)
+        done.append((pipe.submit(src), files))
+        if len(done) == 2:
+            b, fl = done.pop(0)
+            b.sync()
+            for i, data in enumerate(fl):
+                o = oracle.decode(data)
+                assert b.status(i) == 0
+                assert np.array_equal(b.coefs(i), o.coefs) and np.array_equal(b.rgb(i), o.rgb)
+    for b, fl in done:
+        b.sync()
+        for i, data in enumerate(fl):
+            o = oracle.decode(data)
+            assert np.array_equal(b.coefs(i), o.coefs) and np.array_equal(b.rgb(i), o.rgb)
+    pipe.close()
+
+
 def test_unknown_flag_bits_are_refused(ctx):
     data, _ = load_fixture("c420_q85_64x48")
     with pytest.raises(RuntimeError, match="unknown flag"):

@@ -180,9 +180,14 @@ def test_host_code_is_clean_under_sanitizers(tmp_path):
                     os.path.join(pkg, "csrc", "mj_emu.cpp"), *objs, "-lm", "-lpthread"], check=True)
     files = [os.path.join(ROOT, "tests", "golden", n + ".jpg")
              for n in ("c420_q85_100x75_ri3", "g_q75_72x40_ri4", "c422_q95_opt_136x40_ri5", "c444_q90_dqt16_56x40")]
+    import jpeg_decoder_amd as J
+    scans = str(tmp_path / "one_scan_per_component.jpg")      # three scans: the walk goes on after each
+    with open(scans, "wb") as f:
+        f.write(J.synth.encode_jpeg(J.synth.synth_image(100, 75, 3), "4:2:0", 85, 9, scans_per_component=True))
+    files.append(scans)
     r = subprocess.run([exe, "1100", *files], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    assert "runs 4400" in r.stdout
+    assert "runs 5500" in r.stdout
 
 
 def test_reference_viewer_translation_unit_links_against_the_library(tmp_path):

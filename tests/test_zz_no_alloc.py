@@ -66,4 +66,7 @@ def test_static_entry_refuses_what_does_not_fit():
         ctx.decode_static(one, t.data_ptr(), 64, t.data_ptr(), 64, 0)
     with pytest.raises(RuntimeError, match="only MJ_OUT_RGBA"):
         ctx.decode_static(one, t.data_ptr(), t.numel(), t.data_ptr(), t.numel(), binding.MJ_WANT_PLANES)
+    scans = [J.synth.encode_jpeg(J.synth.synth_image(64, 48, 2), "4:2:0", 85, 0, scans_per_component=True)]
+    with pytest.raises(RuntimeError, match="several scans"):
+        ctx.decode_static(scans, t.data_ptr(), t.numel(), t.data_ptr(), t.numel(), 0)
     ctx.close()
