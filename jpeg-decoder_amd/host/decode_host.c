@@ -196,6 +196,57 @@ out:
     return rc;
 }
 
+/* A frame coded in one scan per component: the reference would re-enter decode_scan for every
+ * SOS (decode.c:187-201, :333) and write past its planes from the second on (its MCU counter
+ * runs on, decode.c:125, :473, :504).  Here the whole file goes to the batch entry point once,
+ * which knows such files; the planes of the three scans land in the Image (rows at the Image's
+ * own stride, which is padded to whole MCUs where the scans' planes are padded to whole blocks). */
+static int decode_all_scans(const uint8_t *buf, size_t len, Image *img) {
+    int rc = -1;
+    pthread_mutex_lock(&g_lock);
+    mj_ctx *ctx = default_ctx();
+    mj_batch *b = NULL;
+    uint8_t *tmp = NULL;
+    if (!ctx) goto out;
+    if (mj_batch_create(ctx, &buf, &len, 1, MJ_WANT_PLANES, &b) != 0 || mj_batch_decode(b) != 0) {
+        fprintf(stderr, "mi355jpeg: %s\n", mj_last_error());
+        goto out;
+    }
+    mj_image_info inf;
+    if (mj_batch_image_info(b, 0, &inf) != 0) goto out;
+    SideEntry *se = side_find(img);
+    if (!se) goto out;
+    for (int c = 0; c < inf.ncs && c < img->n_du; c++) {
+        const size_t pw = (size_t) inf.plane_w[c], ph = (size_t) inf.plane_h[c], stride = (size_t) img->width[c];
+        if (pw > stride || stride * ph > se->plane_bytes[c]) {
+            fprintf(stderr, "mi355jpeg: Image plane %d (stride %zu, %zu bytes) does not fit the scan's %zu x %zu plane\n", c, stride,
+                    se->plane_bytes[c], pw, ph);
+            goto out;
+        }
+        uint8_t *t = (uint8_t *) realloc(tmp, (pw * ph) != 0 ? pw * ph : 1);
+        if (!t) goto out;
+        tmp = t;
+        if (mj_batch_copy_plane(b, 0, c, tmp) != 0) {
+            fprintf(stderr, "mi355jpeg: %s\n", mj_last_error());
+            goto out;
+        }
+        for (size_t y = 0; y < ph; y++) memcpy(img->buf[c] + y * stride, tmp + y * pw, pw);
+    }
+    {
+        int64_t mcus = (int64_t) inf.mcus_x * inf.mcus_y;
+        img->mcu = (uint16_t) (mcus > 65535 ? 65535 : mcus);
+    }
+    if (se->batch) mj_batch_destroy(se->batch);
+    se->batch = b;
+    b = NULL;
+    rc = 0;
+out:
+    free(tmp);
+    if (b) mj_batch_destroy(b);
+    pthread_mutex_unlock(&g_lock);
+    return rc;
+}
+
 /* ---- marker walk (decode.c:138-424) ------------------------------------- */
 int decode_jpeg_buffer(uint8_t *buf, size_t len, FrameHeader *fh, Image **img) {
     if (!fh) {
@@ -268,6 +319,13 @@ int decode_jpeg_buffer(uint8_t *buf, size_t len, FrameHeader *fh, Image **img) {
                 if (decode_scan_header(&bs, &sh) != 0) { rc = -1; break; }
                 print_scan_header(&sh);
                 if (!have_qts || !have_hts || !have_fh || !im) { rc = -1; break; }
+                if (sh.nics == 1 && fh->ncs == 3) {
+                    /* one scan per component: all of them at once, and the walk is over */
+                    if (decode_all_scans(buf, len, im) != 0) rc = -1;
+                    bs.encoded_data = (uint8_t *) end;
+                    advance = 0;
+                    break;
+                }
                 bs.encoded_data = seg + seglen;
                 bs.offset = 0;
                 if (decode_scan(&bs, im, fh, &sh, &hts, &qts, ri) != 0) rc = -1;

@@ -12,6 +12,10 @@ int mj_batch_create_scan(mj_ctx *ctx, const uint8_t *entropy, size_t entropy_len
     (void) ctx; (void) entropy; (void) entropy_len; (void) fh; (void) sh; (void) hts; (void) qts; (void) ri; (void) flags; (void) out;
     return -1;
 }
+int mj_batch_create(mj_ctx *ctx, const uint8_t *const *bufs, const size_t *lens, int n, uint32_t flags, mj_batch **out) {
+    (void) ctx; (void) bufs; (void) lens; (void) n; (void) flags; (void) out;
+    return -1;
+}
 void mj_batch_destroy(mj_batch *b) { (void) b; }
 int mj_batch_decode(mj_batch *b) { (void) b; return -1; }
 int mj_batch_image_info(const mj_batch *b, int i, mj_image_info *info) { (void) b; (void) i; (void) info; return -1; }

@@ -316,6 +316,38 @@ def test_dropin_api_like_the_reference_viewer(ctx, name):
     lib.free_frame_header(C.byref(fh))
 
 
+def test_dropin_api_on_a_file_of_one_scan_per_component(ctx, oracle):
+    """decode_jpeg_buffer + ycbcr_rgb on a frame coded in three scans: the Image's planes (at
+    the Image's own stride, padded to whole MCUs) hold the visible samples of every component
+    and the RGB is the restatement's.  The reference itself has no output for such a file."""
+    lib = J.load_library()
+    data, _ = scans_per_component_pair(SCANS_PER_COMPONENT_CASES[1])        # 100 x 75 4:2:0, fitted tables
+    o = oracle.decode(data)
+    buf = C.create_string_buffer(data, len(data) + 16)
+    fh = _FrameHeader()
+    fh.process = -1
+    img = C.POINTER(_Image)()
+    lib.decode_jpeg_buffer.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(_FrameHeader), C.POINTER(C.POINTER(_Image))]
+    assert lib.decode_jpeg_buffer(buf, len(data), C.byref(fh), C.byref(img)) == 0
+    H, W = o.rgb.shape[:2]
+    assert (fh.X, fh.Y, fh.ncs) == (W, H, 3)
+    for c in range(3):
+        p = o.planes[c]
+        stride = img.contents.width[c]
+        assert stride >= p.shape[1]
+        got = np.ctypeslib.as_array(img.contents.buf[c], shape=(p.shape[0], stride))
+        assert np.array_equal(got[:, :p.shape[1]], p), f"Image.buf[{c}] differs"
+    pixels = np.zeros((H, 3 * W), np.uint8)
+    lib.ycbcr_rgb.argtypes = [C.POINTER(_FrameHeader), C.POINTER(_Image), C.c_void_p, C.c_uint16, C.c_uint16, C.c_uint16]
+    assert lib.ycbcr_rgb(C.byref(fh), img, pixels.ctypes.data, W, H, 3 * W) == 0
+    assert np.array_equal(pixels.reshape(H, W, 3), o.rgb)
+    lib.free_img.argtypes = [C.POINTER(_Image)]
+    lib.free_img.restype = None
+    lib.free_img(img)
+    lib.free_frame_header.argtypes = [C.POINTER(_FrameHeader)]
+    lib.free_frame_header(C.byref(fh))
+
+
 def _entropy_start(data):
     i = data.index(b"\xff\xda")
     return i + 2 + ((data[i + 2] << 8) | data[i + 3])
