@@ -388,7 +388,7 @@ int prepare(const uint8_t *const *bufs, const size_t *lens, int n, MjPrep &pp, c
     uint64_t batch_bits = 0;
     for (const MjPrepared &u : pp.img) batch_bits += (uint64_t) u.im.raw_len * 8;
     for (MjPrepared &u : pp.img) {
-        mj_choose_split(u.im.raw_len, u.im.n_ivl, batch_bits, cus * 4u * MJ_SEQ_LANES, &u.im.sub_bits, &u.im.lane_subs);
+        mj_choose_split(u.im.raw_len, u.im.n_ivl, u.im.n_mcu, batch_bits, cus * 4u * MJ_SEQ_LANES, &u.im.sub_bits, &u.im.lane_subs);
     }
     return 0;
 }

@@ -369,28 +369,35 @@ static void tune_load(void) {
     __atomic_store_n(&g_tune.loaded, 1, __ATOMIC_RELEASE);
 }
 
-void mj_choose_split(uint64_t raw_len, uint32_t n_ivl, uint64_t batch_bits, uint32_t chip_lanes, uint32_t *sub_bits, uint32_t *lane_subs) {
+void mj_choose_split(uint64_t raw_len, uint32_t n_ivl, uint32_t n_mcu, uint64_t batch_bits, uint32_t chip_lanes, uint32_t *sub_bits,
+                     uint32_t *lane_subs) {
     tune_load();
     uint64_t bits = raw_len * 8;
     uint64_t avg = bits / (n_ivl ? n_ivl : 1);
     uint64_t lane_bits;
     uint32_t g;
-    if (avg > (uint64_t) MJ_SEQ_LANES * 4096) {
-        /* long intervals: many sequences per interval */
-        lane_bits = 2048;
-        g = 2;
-        if (batch_bits && chip_lanes) {
-            /* A batch whose lanes of that length would not give every SIMD a wavefront or two
-             * is bound by the time one lane takes, not by the chip: shorter lanes then, down to
-             * 256 bits (more lanes to synchronise, all at once).  Measured on 512 x 512 and
-             * 7680 x 4320 files alone and in batches: about one and a half wavefronts per
-             * SIMD is where the two costs meet. */
-            const uint64_t want = batch_bits / (chip_lanes + chip_lanes / 2);
-            uint64_t lb = 256;
-            while (lb < want && lb < 2048) lb *= 2;
-            lane_bits = lb;
-            g = lane_bits >= 2048 ? 2 : 1;
-        }
+    /* A batch whose lanes would not give every SIMD a wavefront or two is bound by the time
+     * one lane takes, not by the chip: shorter lanes then, down to 256 bits (more lanes to
+     * synchronise, all at once).  Measured on 512 x 512, 640 x 480 and 7680 x 4320 files alone
+     * and in batches: about one and a half wavefronts per SIMD is where the two costs meet. */
+    uint64_t fill = 2048;                /* the lane length that fills the chip with this batch, 256 .. 2048 */
+    if (batch_bits && chip_lanes) {
+        const uint64_t want = batch_bits / (chip_lanes + chip_lanes / 2);
+        fill = 256;
+        while (fill < want && fill < 2048) fill *= 2;
+        /* ... but not much shorter than an MCU: a decoder falls into step MCU by MCU, and
+         * subsequences of a fraction of one only multiply the rounds (half an MCU, rounded
+         * down to a power of two, is where 512 x 512 4:2:0 files at 2 bit per pixel and
+         * 640 x 480 4:2:2 files at 5 both do best) */
+        const uint64_t mcu_bits = n_mcu ? bits / n_mcu : 0;
+        while (fill < 2048 && fill * 4 <= mcu_bits) fill *= 2;
+    }
+    /* one wavefront per interval would mean lanes of this length */
+    const uint64_t one_wave = (avg + avg / 16 + MJ_SEQ_LANES - 1) / MJ_SEQ_LANES;
+    if (one_wave > 2 * fill) {
+        /* long intervals (for the batch at hand): many sequences per interval */
+        lane_bits = fill;
+        g = lane_bits >= 2048 ? 2 : 1;
     } else {
         /* one wavefront per interval with a little headroom for uneven intervals */
         lane_bits = (avg + avg / 16 + MJ_SEQ_LANES - 1) / MJ_SEQ_LANES;
@@ -568,7 +575,7 @@ int mj_flatten_image(const MjParsed *p, size_t file_len, MjImageDev *img, MjHuff
     img->ri = p->ri ? p->ri : img->n_mcu;
     img->n_ivl = (img->n_mcu + img->ri - 1) / img->ri;
     img->raw_len = file_len - p->ent_pos;
-    mj_choose_split(img->raw_len, img->n_ivl, 0, 0, &img->sub_bits, &img->lane_subs);   /* the caller may choose again once it knows the batch */
+    mj_choose_split(img->raw_len, img->n_ivl, img->n_mcu, 0, 0, &img->sub_bits, &img->lane_subs);   /* the caller may choose again once it knows the batch */
     img->pitch = (3 * img->X + 3u) & ~3u; /* rows start 4-byte aligned */
     return 0;
 }

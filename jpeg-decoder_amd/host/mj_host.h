@@ -53,10 +53,12 @@ size_t mj_huff_key(const MjParsed *p, uint8_t *key);
 int mj_flatten_image(const MjParsed *p, size_t file_len, MjImageDev *img, MjHuffSet *set, const char **why);
 
 /* How an entropy segment of raw_len bytes in n_ivl restart intervals is cut up:
- * subsequence length (bits, multiple of 32) and subsequences per lane.  batch_bits: the
+ * subsequence length (bits, multiple of 32) and subsequences per lane.  n_mcu: MCUs in the
+ * segment; batch_bits: the
  * entropy-coded bits of the whole batch the image is decoded with, chip_lanes: how many
  * lanes give every SIMD of the device one wavefront; both 0 when not known. */
-void mj_choose_split(uint64_t raw_len, uint32_t n_ivl, uint64_t batch_bits, uint32_t chip_lanes, uint32_t *sub_bits, uint32_t *lane_subs);
+void mj_choose_split(uint64_t raw_len, uint32_t n_ivl, uint32_t n_mcu, uint64_t batch_bits, uint32_t chip_lanes, uint32_t *sub_bits,
+                     uint32_t *lane_subs);
 
 #ifdef __cplusplus
 }
