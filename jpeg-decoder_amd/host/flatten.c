@@ -369,6 +369,9 @@ static void tune_load(void) {
     __atomic_store_n(&g_tune.loaded, 1, __ATOMIC_RELEASE);
 }
 
+#ifndef MJ_SPLIT_FACTOR
+#define MJ_SPLIT_FACTOR 2
+#endif
 void mj_choose_split(uint64_t raw_len, uint32_t n_ivl, uint32_t n_mcu, uint64_t batch_bits, uint32_t chip_lanes, uint32_t *sub_bits,
                      uint32_t *lane_subs) {
     tune_load();
@@ -394,7 +397,7 @@ void mj_choose_split(uint64_t raw_len, uint32_t n_ivl, uint32_t n_mcu, uint64_t 
     }
     /* one wavefront per interval would mean lanes of this length */
     const uint64_t one_wave = (avg + avg / 16 + MJ_SEQ_LANES - 1) / MJ_SEQ_LANES;
-    if (one_wave > 2 * fill) {
+    if (one_wave > MJ_SPLIT_FACTOR * fill) {
         /* long intervals (for the batch at hand): many sequences per interval */
         lane_bits = fill;
         g = lane_bits >= 2048 ? 2 : 1;
