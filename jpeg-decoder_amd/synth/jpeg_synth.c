@@ -446,6 +446,26 @@ int64_t mjs_encode2(const uint8_t *pix, int W, int H, int ncomp, int hs, int vs,
                 q += 64;
             }
         }
+        if ((flags & 4) && ncomp == 3) {
+            /* one scan per component: the DC differences follow the raster order of each
+             * component's own blocks, and the blocks that only pad the MCU grid are not coded */
+            memset(freq, 0, sizeof freq);
+            for (int c = 0; c < 3; c++) {
+                const int hc = c ? 1 : hs, vc = c ? 1 : vs, base = c ? hs * vs + (c - 1) : 0;
+                const int xc = (W * hc + hs - 1) / hs, yc = (H * vc + vs - 1) / vs;
+                const int bw_c = (xc + 7) / 8, bh_c = (yc + 7) / 8;
+                int p1 = 0;
+                int64_t done = 0;
+                for (int by = 0; by < bh_c; by++) {
+                    for (int bx = 0; bx < bw_c; bx++, done++) {
+                        if (ri && done && (done % ri) == 0) p1 = 0;
+                        const int64_t mcu = (int64_t) (by / vc) * mx + bx / hc;
+                        enc_block(NULL, Q + (mcu * bpm + base + (by % vc) * hc + bx % hc) * 64, &p1, NULL, NULL, freq[c ? 2 : 0],
+                                  freq[c ? 3 : 1]);
+                    }
+                }
+            }
+        }
         for (int t = 0; t < (ncomp == 3 ? 4 : 2); t++) fit_table(freq[t], bits[t], vals[t]);
     }
     EncTab dcl, dcc, acl, acc;

@@ -83,6 +83,9 @@ SCANS_PER_COMPONENT_CASES = [
     (131, 77, "4:4:4", 75, 5, False),
     (64, 48, "4:1:1", 60, 0, True),
     (50, 70, "4:4:0", 95, 3, False),
+    (331, 316, "4:4:0", 86, 3, True),       # fitted tables: the DC differences of a component's own raster order
+    (29, 305, "4:1:1", 36, 7, True),
+    (615, 25, "4:4:0", 80, 0, True),
 ]
 
 
