@@ -355,6 +355,18 @@ int prepare_scans(MjPrep &pp, size_t i, const uint8_t *buf, size_t len, MjParsed
     return 0;
 }
 
+/* the cut of every image once more, now that the size of the batch is known */
+int choose_for_batch(MjPrep &pp, const char *who) {
+    uint32_t cus = 0;
+    if (mj_device_cus(&cus) != hipSuccess) return set_err("%s: cannot query the device", who);
+    uint64_t batch_bits = 0;
+    for (const MjPrepared &u : pp.img) batch_bits += (uint64_t) u.im.raw_len * 8;
+    for (MjPrepared &u : pp.img) {
+        mj_choose_split(u.im.raw_len, u.im.n_ivl, u.im.n_mcu, batch_bits, cus * 4u * MJ_SEQ_LANES, &u.im.sub_bits, &u.im.lane_subs);
+    }
+    return 0;
+}
+
 /* host: headers -> descriptors (decode.c:160-415 marker walk + table flattening) */
 int prepare(const uint8_t *const *bufs, const size_t *lens, int n, MjPrep &pp, const char *who) {
     pp.img.resize(n);
@@ -382,15 +394,7 @@ int prepare(const uint8_t *const *bufs, const size_t *lens, int n, MjPrep &pp, c
         pp.img[i].ent = bufs[i] + P.ent_pos;
         mj_parsed_free(&P);
     }
-    /* the cut of every image once more, now that the size of the batch is known */
-    uint32_t cus = 0;
-    if (mj_device_cus(&cus) != hipSuccess) return set_err("%s: cannot query the device", who);
-    uint64_t batch_bits = 0;
-    for (const MjPrepared &u : pp.img) batch_bits += (uint64_t) u.im.raw_len * 8;
-    for (MjPrepared &u : pp.img) {
-        mj_choose_split(u.im.raw_len, u.im.n_ivl, u.im.n_mcu, batch_bits, cus * 4u * MJ_SEQ_LANES, &u.im.sub_bits, &u.im.lane_subs);
-    }
-    return 0;
+    return choose_for_batch(pp, who);
 }
 
 /* host: where every image and every table goes; no HIP call */
@@ -1053,6 +1057,7 @@ int mj_batch_create_scan(mj_ctx *ctx, const uint8_t *entropy, size_t entropy_len
         return set_err("mj_batch_create_scan: %s", why);
     }
     prep.img[0].ent = entropy;
+    if (choose_for_batch(prep, "mj_batch_create_scan")) return -1;
     return batch_build(ctx, prep, flags, out, "mj_batch_create_scan");
 }
 

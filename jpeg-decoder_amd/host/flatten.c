@@ -372,6 +372,7 @@ static void tune_load(void) {
 #ifndef MJ_SPLIT_FACTOR
 #define MJ_SPLIT_FACTOR 2
 #endif
+#define MJ_SMALL_FILE_SEQS 4
 void mj_choose_split(uint64_t raw_len, uint32_t n_ivl, uint32_t n_mcu, uint64_t batch_bits, uint32_t chip_lanes, uint32_t *sub_bits,
                      uint32_t *lane_subs) {
     tune_load();
@@ -397,10 +398,28 @@ void mj_choose_split(uint64_t raw_len, uint32_t n_ivl, uint32_t n_mcu, uint64_t 
     }
     /* one wavefront per interval would mean lanes of this length */
     const uint64_t one_wave = (avg + avg / 16 + MJ_SEQ_LANES - 1) / MJ_SEQ_LANES;
-    if (one_wave > MJ_SPLIT_FACTOR * fill) {
-        /* long intervals (for the batch at hand): many sequences per interval */
-        lane_bits = fill;
-        g = lane_bits >= 2048 ? 2 : 1;
+    /* How many sequences an interval is cut into.  Long intervals (for the batch at hand):
+     * as many as lanes of the batch's length need. */
+    uint64_t k = one_wave > MJ_SPLIT_FACTOR * fill ? (one_wave + fill - 1) / fill : 1;
+    /* A file that is one interval, in a batch large enough for long lanes, is cut into up to
+     * MJ_SMALL_FILE_SEQS sequences as long as their lanes keep 512 bits: the workgroups of
+     * the entropy kernels take their sequences from one image, so a file that is one
+     * sequence leaves all but one wavefront of each of its workgroups idle, and its lanes
+     * are as long as lanes get (a kernel takes at least as long as its longest lane).
+     * Measured on batches of 400 - 1500 files of 24 - 48 KB: 2.69 -> 1.49 ms for 800 files of
+     * 24 KB.  Files with restart markers keep the factor: cutting their many short intervals
+     * costs more in the cross-sequence pass than the shorter lanes save. */
+    if (n_ivl <= 1 && fill >= 1024) {
+        uint64_t want_k = one_wave / 512;
+        if (want_k > MJ_SMALL_FILE_SEQS) want_k = MJ_SMALL_FILE_SEQS;
+        const uint64_t need_k = (one_wave + fill - 1) / fill;
+        k = want_k > need_k ? want_k : need_k;
+        if (k < 1) k = 1;
+    }
+    if (k > 1) {
+        /* a few sequences of long lanes are made equally full */
+        lane_bits = (k <= 8 && fill >= 1024) ? (one_wave + k - 1) / k : fill;
+        g = lane_bits > 1024 ? 2 : 1;
     } else {
         /* one wavefront per interval with a little headroom for uneven intervals */
         lane_bits = (avg + avg / 16 + MJ_SEQ_LANES - 1) / MJ_SEQ_LANES;

@@ -221,6 +221,36 @@ def test_no_restart_long_scan_cross_sequence(ctx, oracle):
     b.close()
 
 
+def test_small_files_without_restart_markers_in_a_large_batch(ctx, oracle):
+    """The lane length follows the size of the whole batch: beside large files, small ones
+    coded as one interval are cut into two to four sequences of their own lane length
+    (a file of 1 to 70 KB takes every branch of that rule).  Each is checked against the
+    restatement, and decodes to the same bytes as alone."""
+    big = [J.synth.config_jpeg("C3", seed=s) for s in (2, 3, 4, 5)]          # 66 Mbit: lanes of 1024 bits
+    small = []
+    for i, (w, h, samp, q) in enumerate([(64, 48, "4:2:0", 60), (160, 120, "4:2:0", 75), (240, 160, "4:4:4", 70),
+                                         (320, 240, "4:2:2", 75), (400, 300, "4:2:0", 85), (640, 480, "4:2:0", 50),
+                                         (640, 480, "4:2:2", 75), (640, 480, "4:4:4", 85), (800, 600, "4:2:0", 90)]):
+        small.append(J.synth.encode_jpeg(J.synth.synth_image(w, h, 50 + i), samp, q, 0, optimise=bool(i & 1)))
+    grey = J.synth.encode_jpeg(J.synth.synth_image(512, 384, 77, grey=True), "4:4:4", 80, 0)
+    files = big[:2] + small + [grey] + big[2:]
+    b = ctx.batch(files, 0)
+    b.decode()
+    st = b.entropy_stats()
+    assert st["multi_seq_intervals"] >= 6, st
+    for i, data in enumerate(files):
+        if 2 <= i < 2 + len(small) + 1:
+            o = oracle.decode(data)
+            _check_image(b, i, o.coefs, None, o.rgb, f"small file {i} ({len(data)} bytes)")
+            alone = ctx.batch([data], 0)
+            alone.decode()
+            assert np.array_equal(alone.rgb(0), b.rgb(i)) and np.array_equal(alone.coefs(0), b.coefs(i))
+            alone.close()
+    o = oracle.decode(big[0])
+    _check_image(b, 0, o.coefs, None, o.rgb, "large neighbour")
+    b.close()
+
+
 @pytest.mark.parametrize("config", ["C1", "C2", "C3"])
 def test_baseline_configs_vs_oracle(ctx, oracle, config):
     """BASELINE configs at full size, one image each, bit-exact against the restatement."""
