@@ -537,9 +537,18 @@ __global__ __launch_bounds__(TPB, MJ_IDCT_WAVES) void mj_k_idct_colour(MjDeviceB
     uint32_t t = (blockIdx.x * WAVES + wave) * share;
     const uint32_t t_end = min(t + share, b.n_idct_tiles);
     if (t >= t_end) return;
+    /* the image of tile t: the last one whose first tile is not past t (a bisection: a walk
+     * over the records costs a dependent load apiece, and a batch may hold thousands) */
     uint32_t ii = 0;
-    MjIdctImg d = load_record(b, 0);
-    while (t >= d.first_tile + d.n_tiles) d = load_record(b, ++ii);
+    for (uint32_t hi = b.n_img - 1; ii < hi;) {
+        const uint32_t mid = (ii + hi + 1) >> 1;
+        if (b.idct_img[mid].first_tile <= t) {
+            ii = mid;
+        } else {
+            hi = mid - 1;
+        }
+    }
+    MjIdctImg d = load_record(b, ii);
     uint32_t mrow = (t - d.first_tile) / d.tiles_x;
     uint32_t m0 = ((t - d.first_tile) - mrow * d.tiles_x) * ((d.geo >> 8) & 0xFFu);
     u4 cv[PASSES];
