@@ -165,9 +165,11 @@ __device__ __forceinline__ LaneRec decode_nowrite(const MjScanCtx &cx, uint32_t 
  * step of the lane-parallel decoder is a hundred instructions.  Here lane l looks up the
  * code that would start at bit l of a 64-bit window, all lanes at once, and packs where the
  * symbol after it starts and how far it moves the zigzag index into one word; the decoder
- * proper is a walk over those words in scalar registers, six instructions per AC symbol.
- * Symbols start in the first 32 bits of a window, so the next one starts inside its 64; the
- * lanes past the span answer "stop".  The words are made again when the window moves on and
+ * proper is a walk over those words in scalar registers, seven instructions per AC symbol.
+ * Every lane's 32 bits come from three stream words, so a symbol may start at any of the 64
+ * bits; the walk leaves the window when the next symbol starts past it (or, for a DC symbol,
+ * so late that the lane its value bits start at does not exist), and the lanes past the
+ * span's end answer "stop".  The words are made again when the window moves on and
  * when the block slot brings other tables.  Symbols are taken one at a time: the symbol runs
  * of the lane-parallel decoder are defined as what that many single steps do. */
 __device__ __forceinline__ uint32_t uni(uint32_t v) {
@@ -177,6 +179,10 @@ __device__ __forceinline__ uint32_t lane_of(uint32_t v, uint32_t l) {      /* v 
     return (uint32_t) __builtin_amdgcn_readlane((int) v, (int) l);
 }
 
+#ifndef MJ_SOLO_SPAN
+#define MJ_SOLO_SPAN 64
+#endif
+constexpr uint32_t SOLO_SPAN = MJ_SOLO_SPAN;   /* symbols that start in this many bits of a window are decoded from it (32 .. 64) */
 constexpr uint32_t SOLO_STOP = 127u;   /* zigzag step of a word that is not a symbol: past the span, or a long code */
 
 /* lane l's word for lookup entry e: bits 0-6 where the next symbol starts, 8-14 the zigzag
@@ -222,7 +228,7 @@ __device__ __forceinline__ LaneRec solo_nowrite(const MjScanCtx &cx, uint32_t p_
         const uint32_t W = (uint32_t) ((((((uint64_t) a) << 32) | bb) << sh) >> 32);
         const uint32_t idx2 = (W >> (32 - MJ_LUT_BITS)) << 1;
         const uint32_t base = p & ~31u;
-        const uint32_t lim = min(32u, end - base);             /* a symbol is decoded when it starts before this */
+        const uint32_t lim = min(SOLO_SPAN, end - base);       /* a symbol is decoded when it starts before this */
         uint32_t o = p - base;                                 /* 0 .. 31, < lim */
         uint32_t Edc = 0, Eac = 0, Ndc = 0, Nac = 0, have = 0xFFFFFFFFu;
         for (;;) {
@@ -234,7 +240,9 @@ __device__ __forceinline__ LaneRec solo_nowrite(const MjScanCtx &cx, uint32_t p_
                 have = slot >> 2;
             }
             if (k == 0) {
-                /* the DC symbol: the difference is `size` bits after the code, then EXTEND (decode.c:684-686) */
+                /* the DC symbol: the difference is `size` bits after the code, then EXTEND (decode.c:684-686);
+                 * its value bits are taken from the lane the code ends at, which must exist */
+                if (o + 16u > 63u) break;
                 uint32_t x = lane_of(Ndc, o);
                 if (((x >> 8) & 127u) == SOLO_STOP) {          /* o < lim here: a long code */
                     const uint32_t e = uni(mj_long_code_at(cx, mj_slot_tdc(slot), lane_of(W, o), 0, lane_of(Edc, o)));
@@ -254,7 +262,7 @@ __device__ __forceinline__ LaneRec solo_nowrite(const MjScanCtx &cx, uint32_t p_
             }
             /* AC symbols up to the end of the block, of the span, or a long code */
             uint32_t x = 0;
-            while (k < 64u) {
+            while ((k | o) < 64u) {                            /* the block goes on and the symbol starts inside the window */
                 x = lane_of(Nac, o);
                 k += (x >> 8) & 127u;
                 o = x & 127u;

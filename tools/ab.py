@@ -1,4 +1,4 @@
-"""A/B timing of library builds on one GPU box: python tools/ab.py libA.so libB.so [workload] [reps]
+"""A/B timing of library builds on one GPU box: python tools/ab.py libA.so libB.so [libC.so ...] [workload] [reps]
 Each build decodes the same batch in its own process, alternating, and the per-stage times are printed."""
 import os, subprocess, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -22,9 +22,10 @@ for i in range(20):
 torch.cuda.synchronize()
 print(json.dumps({k: round(v[0] / max(v[1], 1), 4) for k, v in bt.kernel_ms().items()}))
 ''' % ROOT
-libs = sys.argv[1:3]
-wl = sys.argv[3] if len(sys.argv) > 3 else "C3"
-reps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+libs = [a for a in sys.argv[1:] if a.endswith(".so")]        # two builds or more
+rest = [a for a in sys.argv[1:] if not a.endswith(".so")]
+wl = rest[0] if rest else "C3"
+reps = int(rest[1]) if len(rest) > 1 else 3
 for r in range(reps):
     for lib in libs:
         out = subprocess.run([sys.executable, "-c", CHILD, os.path.abspath(lib), wl], capture_output=True, text=True, timeout=300)
