@@ -1,5 +1,5 @@
 """A/B timing of library builds on one GPU box: python tools/ab.py libA.so libB.so [libC.so ...] [workload] [reps]
-Each build decodes the same batch in its own process, alternating, and the per-stage times are printed."""
+Each build decodes the same batch (MJ_AB_BATCH images, 64 if unset) in its own process, alternating, and the per-stage times are printed."""
 import os, subprocess, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r'''
@@ -10,7 +10,7 @@ binding.LIB_PATH = sys.argv[1]
 import bench, torch
 import jpeg_decoder_amd as J
 from jpeg_decoder_amd.shard import shard_seeds
-files = bench.generate(sys.argv[2], shard_seeds(64 if sys.argv[2] != "C4" else 4, 0, 1), 8)
+files = bench.generate(sys.argv[2], shard_seeds(int(os.environ.get("MJ_AB_BATCH", "64")) if sys.argv[2] != "C4" else 4, 0, 1), 16)
 ctx = J.Context(0)
 bt = ctx.batch(files, binding.MJ_TIMING)
 for i in range(3):
