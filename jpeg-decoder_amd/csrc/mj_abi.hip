@@ -75,7 +75,7 @@ constexpr size_t kStaticMetaBytes = 4u << 20;   /* page-locked mirror of the met
 /* offsets of every device buffer inside its region (all multiples of 256) */
 struct Offsets {
     /* meta */
-    size_t img, sets, tile_img, wg_img, idct_img, comb, meta_bytes;
+    size_t img, sets, tile_img, wg_img, pair_grp, idct_img, comb, meta_bytes;
     /* state */
     size_t dyn, tile_cnt, tile_base, ivl_start, ivl_seq, seq_ivl, seq_sub, seq_entry, seq_seen, seq_flag, multi, multi_count,
         stats, state_bytes;
@@ -134,7 +134,8 @@ struct mj_batch {
     std::vector<MjImageDev> img;
     std::vector<mj_image_info> info;
     std::vector<MjHuffSet> sets;
-    std::vector<uint32_t> tile_img, wg_img;
+    std::vector<uint32_t> tile_img, wg_img, pair_grp;
+    uint32_t n_busy_groups = 0;
     std::vector<MjIdctImg> idct_img;
     size_t n_files = 0;                /* img, info, idct_img also hold the extra units of files with several scans */
     std::vector<MjMultiScan> multi;
@@ -471,6 +472,8 @@ int layout(mj_batch *b, const MjPrep &pp, uint32_t flags, bool may_span) {
     b->sets = pp.sets;
     b->tile_img.clear();
     b->wg_img.clear();
+    b->pair_grp.clear();
+    b->n_busy_groups = 0;
     b->idct_img.assign((size_t) n, MjIdctImg{});
     b->n_files = pp.n_files;
     b->multi = pp.multi;
@@ -529,6 +532,12 @@ int layout(mj_batch *b, const MjPrep &pp, uint32_t flags, bool may_span) {
         n_idct += iw;
         b->tile_img.insert(b->tile_img.end(), im.n_tiles, (uint32_t) i);
         b->wg_img.insert(b->wg_img.end(), wgs, (uint32_t) i);
+        for (uint32_t g = 0; g < wgs; g += 2) b->pair_grp.push_back(im.wg_first + g);
+        {
+            const uint64_t by_bits = im.raw_len * 8 / seq_bits;
+            const uint64_t seqs_lb = by_bits > im.n_ivl ? by_bits : im.n_ivl;
+            b->n_busy_groups += (uint32_t) ((seqs_lb + MJ_WG_SEQS - 1) / MJ_WG_SEQS);
+        }
         if (n_tiles >= (1ull << 31) || n_seq >= (1ull << 31) || n_rec >= (1ull << 31) || n_idct >= (1ull << 31) || n_ivl >= (1ull << 31)) {
             return set_err("batch too large");
         }
@@ -629,6 +638,7 @@ int layout(mj_batch *b, const MjPrep &pp, uint32_t flags, bool may_span) {
     o.sets = m.take(b->sets.size() * sizeof(MjHuffSet));
     o.tile_img = m.take(n_tiles * 4);
     o.wg_img = m.take(n_wg * 4);
+    o.pair_grp = m.take(b->pair_grp.size() * 4);
     o.idct_img = m.take((uint64_t) n * sizeof(MjIdctImg));
     o.comb = m.take(b->comb.size() * sizeof(MjCombine));
     o.meta_bytes = m.off;
@@ -665,6 +675,9 @@ void bind(mj_batch *b, uint8_t *meta, uint8_t *state, uint8_t *work, uint8_t *co
     d.sets = reinterpret_cast<const MjHuffSet *>(meta + o.sets);
     d.tile_img = reinterpret_cast<const uint32_t *>(meta + o.tile_img);
     d.wg_img = reinterpret_cast<const uint32_t *>(meta + o.wg_img);
+    d.pair_grp = reinterpret_cast<const uint32_t *>(meta + o.pair_grp);
+    d.n_sync_pairs = (uint32_t) b->pair_grp.size();
+    d.n_busy_groups = b->n_busy_groups;
     d.idct_img = reinterpret_cast<const MjIdctImg *>(meta + o.idct_img);
     d.comb = reinterpret_cast<const MjCombine *>(meta + o.comb);
     d.dyn = reinterpret_cast<MjImageDyn *>(state + o.dyn);
@@ -754,6 +767,7 @@ int upload(mj_batch *b, const std::vector<MjPrepared> &prep, uint8_t *meta, uint
     memcpy(mh + o.sets, b->sets.data(), b->sets.size() * sizeof(MjHuffSet));
     memcpy(mh + o.tile_img, b->tile_img.data(), b->tile_img.size() * 4);
     memcpy(mh + o.wg_img, b->wg_img.data(), b->wg_img.size() * 4);
+    memcpy(mh + o.pair_grp, b->pair_grp.data(), b->pair_grp.size() * 4);
     memcpy(mh + o.idct_img, b->idct_img.data(), n * sizeof(MjIdctImg));
     if (!b->comb.empty()) memcpy(mh + o.comb, b->comb.data(), b->comb.size() * sizeof(MjCombine));
     HIP_TRY(hipMemcpyAsync(meta, mh, o.meta_bytes, hipMemcpyHostToDevice, s));

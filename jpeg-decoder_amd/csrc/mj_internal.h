@@ -60,6 +60,9 @@ struct MjDeviceBatch {
     uint2 *multi;            /* (image, interval) of intervals longer than one sequence */
     uint32_t *multi_count;
     const uint32_t *wg_img;  /* [n_entropy_wg] image of each entropy workgroup */
+    const uint32_t *pair_grp; /* [n_sync_pairs] first workgroup of every pair of workgroups of one image (an image's last pair may be a single one) */
+    uint32_t n_sync_pairs;
+    uint32_t n_busy_groups;  /* lower bound on the workgroups that will hold work: per image the larger of its restart intervals and its bytes over a sequence's, in eights */
     const MjIdctImg *idct_img; /* [n_img] what the IDCT + colour kernel reads per image */
     const MjCombine *comb;   /* [n_comb] frames coded in one scan per component */
     uint32_t n_comb, comb_max_x, comb_max_y;

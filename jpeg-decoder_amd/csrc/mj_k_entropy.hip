@@ -49,16 +49,24 @@ namespace {
 
 constexpr int WAVES = 4;             /* writing, serial kernels */
 constexpr int TPB = WAVES * 64;
-/* The synchronisation kernel comes in two shapes.  SPW = 1: a sequence per wavefront, eight
+/* The synchronisation kernel comes in three shapes.  SPW = 1: a sequence per wavefront, eight
  * wavefronts per workgroup, a lane takes the subsequences a lane of the writing pass takes.
  * SPW = 2: a sequence per half wavefront, four wavefronts per workgroup, a lane takes twice
  * as many subsequences in the cold pass; half as many decoders have to go on into the
  * rounds, and five workgroups fit a CU (by their LDS) instead of four (by their
  * wavefronts), so that all the workgroups of a large batch are on the chip from the start
- * instead of the last of them starting when the first have finished.  A batch too small to
- * fill the chip is bound by the time a lane takes and keeps the short lanes.  The records
- * are per subsequence, so the two passes need not agree on the lanes. */
-constexpr int SYNC_TPB_MAX = MJ_WG_SEQS * 64;
+ * instead of the last of them starting when the first have finished.  SPW = 4: a sequence per
+ * quarter wavefront and two groups of sequences to a workgroup (still four wavefronts), a
+ * lane takes four times the subsequences in the cold pass and a quarter of the decoders go
+ * on into the rounds: less work, longer chains, for batches so large that the workgroups
+ * take several turns on the chip and the chains of one turn hide behind the cold passes of
+ * the next (C3: 2.40 -> 2.04 ms at 256 images, 1.43 -> 1.30 at 128; 0.88 -> 1.18 at 64,
+ * where it is not used).  A batch too small to fill the chip is bound by the time a lane
+ * takes and keeps the short lanes.  The records are per subsequence, so the passes need not
+ * agree on the lanes. */
+#ifndef MJ_SYNC4_MIN_GROUPS_PER_CU
+#define MJ_SYNC4_MIN_GROUPS_PER_CU 8
+#endif
 #ifndef MJ_SOLO_MAX
 #define MJ_SOLO_MAX 8
 #endif
@@ -348,10 +356,16 @@ struct SeqGeo {           /* one sequence of the workgroup, in LDS */
 
 /* A decoder that has to go on, in one word: bits 0-5 zigzag index, 6-9 block slot, 10-14
  * how many bits past the start of its next subsequence it stands (a symbol that crosses a
- * boundary ends at most 30 bits after it), 15-17 sequence within the workgroup, 18-27 the
+ * boundary ends at most 30 bits after it), 15-18 sequence within the workgroup, 19-28 the
  * subsequence (within the sequence) to decode next. */
 __device__ __forceinline__ uint32_t pack_task(uint32_t kc, uint32_t over, uint32_t seq, uint32_t u) {
-    return (kc & 63u) | ((kc >> 8) << 6) | (over << 10) | (seq << 15) | (u << 18);
+    return (kc & 63u) | ((kc >> 8) << 6) | (over << 10) | (seq << 15) | (u << 19);
+}
+__device__ __forceinline__ uint32_t task_seq(uint32_t t) {
+    return (t >> 15) & 15u;
+}
+__device__ __forceinline__ uint32_t task_sub(uint32_t t) {
+    return t >> 19;
 }
 
 __device__ __forceinline__ void push_task(bool have, uint32_t task, uint32_t *queue, uint32_t *count) {
@@ -364,26 +378,35 @@ __device__ __forceinline__ void push_task(bool have, uint32_t task, uint32_t *qu
     if (have) queue[base + __popcll(mask & ((1ull << lane) - 1ull))] = task;
 }
 
+constexpr int sync_groups(int spw) {       /* groups of MJ_WG_SEQS sequences one workgroup takes */
+    return spw == 4 ? 2 : 1;
+}
+constexpr int sync_threads(int spw) {
+    return sync_groups(spw) * MJ_WG_SEQS * (MJ_SEQ_LANES / spw);
+}
 template <int SYNC_SPW>
-__global__ __launch_bounds__(MJ_WG_SEQS * 64 / SYNC_SPW, SYNC_SPW == 2 ? 5 : 4) void mj_k_entropy_sync(MjDeviceBatch b) {
+__global__ __launch_bounds__(sync_threads(SYNC_SPW), SYNC_SPW >= 2 ? 5 : 4) void mj_k_entropy_sync(MjDeviceBatch b) {
     constexpr int SYNC_SEQ_LANES = MJ_SEQ_LANES / SYNC_SPW;
-    constexpr int SYNC_TPB = MJ_WG_SEQS * 64 / SYNC_SPW;
+    constexpr int SYNC_SEQS = sync_groups(SYNC_SPW) * MJ_WG_SEQS;
+    constexpr int SYNC_TPB = sync_threads(SYNC_SPW);
     constexpr uint32_t SYNC_WAVES = SYNC_TPB / 64;
-    const uint32_t ii = b.wg_img[blockIdx.x];
+    /* the first group of the block; with two groups to a block, the second is the next of the same image (if it has one) */
+    const uint32_t grp0 = (SYNC_SPW == 4) ? b.pair_grp[blockIdx.x] : blockIdx.x;
+    const uint32_t ii = b.wg_img[grp0];
     const MjImageDev &im = b.img[ii];
     const uint32_t n_seq = b.dyn[ii].n_seq;
-    const uint32_t seq0 = (blockIdx.x - im.wg_first) * MJ_WG_SEQS;
+    const uint32_t seq0 = (grp0 - im.wg_first) * MJ_WG_SEQS;
     if (seq0 >= n_seq) return;
 
     /* dynamic LDS: [tables][sequence geometry][3 queue counters][two queues][symbol-run tables] */
     SeqGeo *s_geo = reinterpret_cast<SeqGeo *>(lds_after_dc(b, 0));
-    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_geo + MJ_WG_SEQS);
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_geo + SYNC_SEQS);
     uint32_t *s_queue = s_cnt + 4;
     unsigned char *s_pairs = reinterpret_cast<unsigned char *>(s_queue + 2 * SYNC_TPB);
 
     const uint32_t S = im.sub_bits, G = im.lane_subs, SQ = MJ_SEQ_LANES * G;
     load_tables(b, im, s_pairs, true);
-    if (threadIdx.x < MJ_WG_SEQS) {
+    if (threadIdx.x < SYNC_SEQS) {
         SeqGeo sg = {0, 0, 0, 0, 0, 0, {0, 0}};
         const uint32_t seq = seq0 + threadIdx.x;
         if (seq < n_seq) {
@@ -465,7 +488,7 @@ __global__ __launch_bounds__(MJ_WG_SEQS * 64 / SYNC_SPW, SYNC_SPW == 2 ? 5 : 4) 
         if (solo) {
             for (uint32_t t = wave; t < total; t += SYNC_WAVES) {
                 const uint32_t tw = uni(q_from[t]);
-                const uint32_t sw = (tw >> 15) & 7u, u = tw >> 18;
+                const uint32_t sw = task_seq(tw), u = task_sub(tw);
                 const uint32_t kc = (tw & 63u) | (((tw >> 6) & 15u) << 8);
                 const SeqGeo g = s_geo[sw];
                 MjSubRec *dst = b.rec + g.rec_base + u;
@@ -484,7 +507,7 @@ __global__ __launch_bounds__(MJ_WG_SEQS * 64 / SYNC_SPW, SYNC_SPW == 2 ? 5 : 4) 
             uint32_t task = 0;
             if (threadIdx.x < total) {
                 const uint32_t tk = q_from[threadIdx.x];
-                const uint32_t sw = (tk >> 15) & 7u, u = tk >> 18;
+                const uint32_t sw = task_seq(tk), u = task_sub(tk);
                 const uint32_t kc = (tk & 63u) | (((tk >> 6) & 15u) << 8);
                 const SeqGeo g = s_geo[sw];
                 MjSubRec *dst = b.rec + g.rec_base + u;
@@ -909,12 +932,19 @@ hipError_t mj_launch_entropy(const MjDeviceBatch &b, hipStream_t s) {
     uint32_t cus = 0;
     const hipError_t e = mj_device_cus(&cus);
     if (e != hipSuccess) return e;
-    /* long lanes once the short ones would put four wavefronts or more on every SIMD */
-    const bool two = force_spw ? force_spw == 2 : b.n_entropy_wg >= 2 * cus;
-    const uint32_t tpb = SYNC_TPB_MAX / (two ? 2 : 1);
-    const size_t lds = table_lds(b, 0) + MJ_WG_SEQS * sizeof(SeqGeo) + 4 * sizeof(uint32_t) + 2 * tpb * sizeof(uint32_t) +
+    /* long lanes once the short ones would put four wavefronts or more on every SIMD; longer
+     * ones still, two groups of sequences to a workgroup, once the groups that hold work
+     * (the host knows a lower bound) are several times what the chip holds at once: the
+     * ends of the chains then hide behind other workgroups' cold passes, and what counts is
+     * how few decoders go on into the rounds */
+    const int spw = force_spw ? force_spw : (b.n_busy_groups >= MJ_SYNC4_MIN_GROUPS_PER_CU * cus) ? 4 : (b.n_entropy_wg >= 2 * cus) ? 2 : 1;
+    const uint32_t tpb = spw == 4 ? sync_threads(4) : spw == 2 ? sync_threads(2) : sync_threads(1);
+    const uint32_t seqs = (spw == 4 ? sync_groups(4) : 1) * MJ_WG_SEQS;
+    const size_t lds = table_lds(b, 0) + seqs * sizeof(SeqGeo) + 4 * sizeof(uint32_t) + 2 * tpb * sizeof(uint32_t) +
                        (size_t) b.max_nac * sizeof(MjHuffRun) + pad;
-    if (two) {
+    if (spw == 4) {
+        hipLaunchKernelGGL(mj_k_entropy_sync<4>, dim3(b.n_sync_pairs), dim3(tpb), lds, s, b);
+    } else if (spw == 2) {
         hipLaunchKernelGGL(mj_k_entropy_sync<2>, dim3(b.n_entropy_wg), dim3(tpb), lds, s, b);
     } else {
         hipLaunchKernelGGL(mj_k_entropy_sync<1>, dim3(b.n_entropy_wg), dim3(tpb), lds, s, b);

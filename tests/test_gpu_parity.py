@@ -610,6 +610,34 @@ def test_full_batch_of_64_every_image_vs_oracle(ctx, config):
     assert not bad, f"{config}: images {bad} differ from the restatement"
 
 
+def test_batch_large_enough_for_the_longest_lanes(ctx, oracle):
+    """The synchronisation kernel takes its third shape (a sequence per quarter wavefront, two
+    groups of sequences per workgroup) when the workgroup groups that are sure to hold work
+    number eight per compute unit or more.  Seventeen 512 x 512 files with a restart interval
+    per MCU (1,024 intervals = 128 groups each) make such a batch without much data; beside
+    them files whose intervals are long enough for rounds (4K, an interval per MCU row), one
+    scan without restart markers (cross-sequence pass), a grey and a 4:4:4 file.  Every image
+    is compared with the restatement."""
+    import torch
+    tiny = [J.synth.encode_jpeg(J.synth.synth_image(512, 512, 900 + s), "4:2:0", 80, 1) for s in range(17)]
+    assert 17 * (1024 // 8) >= 8 * torch.cuda.get_device_properties(0).multi_processor_count
+    rows = [J.synth.config_jpeg("C3", seed=s) for s in (31, 32)]
+    long_scan = J.synth.encode_jpeg(J.synth.synth_image(1024, 768, 5), "4:2:0", 85, 0)
+    grey = J.synth.encode_jpeg(J.synth.synth_image(640, 480, 6, grey=True), "4:4:4", 75, J.synth.mcus_per_row(640, "4:4:4", True))
+    full = J.synth.encode_jpeg(J.synth.synth_image(1920, 1080, 7), "4:4:4", 85, J.synth.mcus_per_row(1920, "4:4:4", False), optimise=True)
+    files = tiny[:9] + [rows[0], long_scan] + tiny[9:] + [grey, rows[1], full]
+    b = ctx.batch(files, 0)
+    b.decode()
+    b.sync()
+    st = b.entropy_stats()
+    assert st["multi_seq_intervals"] >= 1, st
+    for i, data in enumerate(files):
+        o = oracle.decode(data)
+        assert b.status(i) == 0
+        _check_image(b, i, o.coefs, None, o.rgb, f"file {i} ({len(data)} bytes)")
+    b.close()
+
+
 C5_CASES = [(mode, q, opt) for mode in ("grey", "4:2:2", "4:2:0") for q in (50, 75, 95) for opt in (False, True)]
 
 
