@@ -372,7 +372,7 @@ def main():
     desc = WORKLOADS[args.workload][4]
     if args.batch <= 0:
         # a larger batch amortises the ends of the kernels, above all the serial tail of the entropy
-        # synchronisation: C3 on one GPU 181 GP/s at 64 images, 191 at 128, 203 at 256, 211 at 512
+        # synchronisation: C3 on one GPU 181 GP/s at 64 images, 196 at 128, 212 at 256
         args.batch = {"C3": 256, "C4": 4}.get(args.workload, 64)
     if args.workload == "C4":
         args.batch = min(args.batch, 4)
