@@ -100,11 +100,14 @@ def _gen_one(args):
 
 
 def generate(workload, seeds, workers):
-    cache = os.environ.get("MJ_BENCH_CACHE", "/tmp/mj_bench_cache")
-    try:
-        os.makedirs(cache, exist_ok=True)
-    except OSError:
-        cache = None
+    # generated files are kept only where the caller names a directory (the profiling passes of
+    # profiles/collect.sh run the benchmark five times): a default batch is 2 GB of JPEGs per rank
+    cache = os.environ.get("MJ_BENCH_CACHE") or None
+    if cache:
+        try:
+            os.makedirs(cache, exist_ok=True)
+        except OSError:
+            cache = None
     jobs = [(workload, s, cache) for s in seeds]
     if workers <= 1 or len(jobs) == 1:
         return [_gen_one(j) for j in jobs]

@@ -9,6 +9,7 @@ tag=${1:-prof}
 out=gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
+export MJ_BENCH_CACHE=/tmp/mj_bench_cache     # the passes below decode the same generated files
 # the profiled command: the benchmark's timed region alone -- no CPU leg, no forked input
 # generation (the profiler preload does not survive forks), no single-image and no
 # pinned-host legs, whose launches of the same kernels on other sizes, or overlapping each

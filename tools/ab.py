@@ -4,6 +4,7 @@ import os, subprocess, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r'''
 import os, sys, json
+os.environ.setdefault("MJ_BENCH_CACHE", "/tmp/mj_bench_cache")      # the builds decode the same generated files
 sys.path.insert(0, %r)
 from jpeg_decoder_amd import binding
 binding.LIB_PATH = sys.argv[1]

@@ -1,5 +1,6 @@
 """Where the synchronisation kernel's time goes (library built with -DMJ_SYNC_TRACE): python tools/trace_sync.py lib.so [workload]"""
 import os, sys
+os.environ.setdefault("MJ_BENCH_CACHE", "/tmp/mj_bench_cache")
 sys.path.insert(0, os.getcwd())
 from jpeg_decoder_amd import binding
 binding.LIB_PATH = os.path.abspath(sys.argv[1])
