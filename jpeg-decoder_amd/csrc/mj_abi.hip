@@ -24,6 +24,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <chrono>
+#include <algorithm>
 #include <vector>
 
 #include "../host/mj_host.h"
@@ -519,9 +520,6 @@ int layout(mj_batch *b, const MjPrep &pp, uint32_t flags, bool may_span) {
         n_seq += im.seq_cap;
         im.rec_off = (uint32_t) n_rec;
         n_rec += im.seq_cap * seq_subs;
-        im.wg_first = (uint32_t) n_wg;
-        const uint32_t wgs = (im.seq_cap + MJ_WG_SEQS - 1) / MJ_WG_SEQS;
-        n_wg += wgs;
         uint64_t mc = im.raw_len * 8 / seq_bits;
         im.multi_cap = (uint32_t) (mc < im.n_ivl ? mc : im.n_ivl);
         n_multi += im.multi_cap;
@@ -531,8 +529,6 @@ int layout(mj_batch *b, const MjPrep &pp, uint32_t flags, bool may_span) {
         b->idct_img[i] = idct_record(im, (uint32_t) n_idct);
         n_idct += iw;
         b->tile_img.insert(b->tile_img.end(), im.n_tiles, (uint32_t) i);
-        b->wg_img.insert(b->wg_img.end(), wgs, (uint32_t) i);
-        for (uint32_t g = 0; g < wgs; g += 2) b->pair_grp.push_back(im.wg_first + g);
         {
             const uint64_t by_bits = im.raw_len * 8 / seq_bits;
             const uint64_t seqs_lb = by_bits > im.n_ivl ? by_bits : im.n_ivl;
@@ -602,6 +598,26 @@ int layout(mj_batch *b, const MjPrep &pp, uint32_t flags, bool may_span) {
         comb_max_x = mm.X > comb_max_x ? mm.X : comb_max_x;
         comb_max_y = mm.Y > comb_max_y ? mm.Y : comb_max_y;
         b->comb.push_back(cb);
+    }
+
+    /* Entropy workgroups, in the order the grids take them: the images whose lanes are longest
+     * first (a workgroup lasts about as long as its lanes are; in a mixed batch the long ones
+     * started last would end the kernels alone), files of one lane length in the order given. */
+    {
+        std::vector<uint32_t> order((size_t) n);
+        for (int i = 0; i < n; i++) order[(size_t) i] = (uint32_t) i;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+            return (uint64_t) b->img[x].sub_bits * b->img[x].lane_subs > (uint64_t) b->img[y].sub_bits * b->img[y].lane_subs;
+        });
+        for (uint32_t i : order) {
+            MjImageDev &im = b->img[i];
+            im.wg_first = (uint32_t) n_wg;
+            const uint32_t wgs = (im.seq_cap + MJ_WG_SEQS - 1) / MJ_WG_SEQS;
+            n_wg += wgs;
+            b->wg_img.insert(b->wg_img.end(), wgs, i);
+            for (uint32_t g = 0; g < wgs; g += 2) b->pair_grp.push_back(im.wg_first + g);
+        }
+        if (n_wg >= (1ull << 31)) return set_err("batch too large");
     }
 
     MjDeviceBatch &d = b->d;
