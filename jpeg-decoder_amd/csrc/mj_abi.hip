@@ -25,6 +25,7 @@
 #include <cstring>
 #include <chrono>
 #include <algorithm>
+#include <thread>
 #include <vector>
 
 #include "../host/mj_host.h"
@@ -369,32 +370,134 @@ int choose_for_batch(MjPrep &pp, const char *who) {
     return 0;
 }
 
-/* host: headers -> descriptors (decode.c:160-415 marker walk + table flattening) */
+/* one file of a call: parsed and flattened into pp.img[i]; a file of several scans is only
+ * recognised here when `defer` is given (its units are appended to pp.img, which is not for
+ * several threads at once) and its index left there */
+int prepare_file(MjPrep &pp, MjPrepared &dst, size_t i, const uint8_t *buf, size_t len, bool *defer, MjPrep *units_into,
+                 char *msg, size_t msg_cap) {
+    MjParsed P;
+    const char *why = "?";
+    if (!buf) {
+        snprintf(msg, msg_cap, "null buffer");
+        return -1;
+    }
+    if (mj_parse_headers(buf, len, &P, &why) != 0) {
+        snprintf(msg, msg_cap, "%s", why);       /* the parser freed what it had */
+        return -1;
+    }
+    if (P.sh.nics == 1 && P.fh.ncs == 3) {
+        if (defer) {
+            *defer = true;
+            mj_parsed_free(&P);
+            return 0;
+        }
+        bool freed = false;
+        if (prepare_scans(*units_into, i, buf, len, P, &why, freed) != 0) {
+            if (!freed) mj_parsed_free(&P);
+            snprintf(msg, msg_cap, "%s", why);
+            return -1;
+        }
+        mj_parsed_free(&P);
+        return 0;
+    }
+    if (prepare_one(pp, dst, P, len, &why) != 0) {
+        mj_parsed_free(&P);
+        snprintf(msg, msg_cap, "%s", why);
+        return -1;
+    }
+    dst.ent = buf + P.ent_pos;
+    mj_parsed_free(&P);
+    return 0;
+}
+
+/* host: headers -> descriptors (decode.c:160-415 marker walk + table flattening).  Files are
+ * independent, and a file with Huffman tables of its own costs tens of microseconds (the
+ * lookup tables are built from them): a call of many files is spread over a few threads,
+ * each with the table sets it meets, which are merged by key afterwards; files of several
+ * scans, whose units go to the end of the list, are taken last, in order, by the caller's
+ * thread. */
+constexpr int kPrepareThreads = 4;
+constexpr int kPrepareMinFilesPerThread = 16;
+
 int prepare(const uint8_t *const *bufs, const size_t *lens, int n, MjPrep &pp, const char *who) {
     pp.img.resize(n);
     pp.n_files = (size_t) n;
-    for (int i = 0; i < n; i++) {
-        MjParsed P;
-        const char *why = "?";
-        if (!bufs[i]) return set_err("%s: image %d: null buffer", who, i);
-        if (mj_parse_headers(bufs[i], lens[i], &P, &why) != 0) {
-            return set_err("%s: image %d: %s", who, i, why);   /* the parser freed what it had */
-        }
-        if (P.sh.nics == 1 && P.fh.ncs == 3) {
-            bool freed = false;
-            if (prepare_scans(pp, (size_t) i, bufs[i], lens[i], P, &why, freed) != 0) {
-                if (!freed) mj_parsed_free(&P);
-                return set_err("%s: image %d: %s", who, i, why);
+    char msg[256];
+    const int n_thr = std::min(kPrepareThreads, n / kPrepareMinFilesPerThread);
+    if (n_thr < 2) {
+        for (int i = 0; i < n; i++) {
+            if (prepare_file(pp, pp.img[i], (size_t) i, bufs[i], lens[i], nullptr, &pp, msg, sizeof msg) != 0) {
+                return set_err("%s: image %d: %s", who, i, msg);
             }
-            mj_parsed_free(&P);
-            continue;
         }
-        if (prepare_one(pp, pp.img[i], P, lens[i], &why) != 0) {
-            mj_parsed_free(&P);
-            return set_err("%s: image %d: %s", who, i, why);
+        return choose_for_batch(pp, who);
+    }
+    struct Share {
+        MjPrep local;                 /* the table sets this thread met; img unused */
+        std::vector<int> deferred;    /* files of several scans */
+        int bad = -1;                 /* first file that was refused */
+        char msg[256];
+    };
+    std::vector<Share> share((size_t) n_thr);
+    auto work = [&](int t) {
+        Share &sh = share[(size_t) t];
+        const int i0 = (int) ((int64_t) n * t / n_thr), i1 = (int) ((int64_t) n * (t + 1) / n_thr);
+        for (int i = i0; i < i1; i++) {
+            bool defer = false;
+            if (prepare_file(sh.local, pp.img[i], (size_t) i, bufs[i], lens[i], &defer, nullptr, sh.msg, sizeof sh.msg) != 0) {
+                sh.bad = i;
+                return;
+            }
+            if (defer) sh.deferred.push_back(i);
         }
-        pp.img[i].ent = bufs[i] + P.ent_pos;
-        mj_parsed_free(&P);
+    };
+    {
+        std::vector<std::thread> pool;
+        for (int t = 1; t < n_thr; t++) {
+            pool.emplace_back([&work, t]() {
+                work(t);
+                mj_flatten_thread_done();      /* the thread ends here: its table cache with it */
+            });
+        }
+        work(0);
+        for (std::thread &th : pool) th.join();
+    }
+    for (const Share &sh : share) {        /* shares are in file order: the first refusal is reported */
+        if (sh.bad >= 0) return set_err("%s: image %d: %s", who, sh.bad, sh.msg);
+    }
+    /* one list of sets: those of every share looked up by key, new ones appended */
+    for (int t = 0; t < n_thr; t++) {
+        Share &sh = share[(size_t) t];
+        std::vector<uint32_t> global(sh.local.sets.size());
+        for (size_t k = 0; k < sh.local.sets.size(); k++) {
+            const uint8_t *key = &sh.local.keys[k * MJ_HUFF_KEY_BYTES];
+            const size_t klen = sh.local.key_len[k];
+            int si = find_set(pp, key, klen);
+            if (si < 0) {
+                pp.sets.push_back(sh.local.sets[k]);
+                si = (int) pp.sets.size() - 1;
+                pp.keys.resize(pp.sets.size() * MJ_HUFF_KEY_BYTES);
+                memcpy(&pp.keys[(size_t) si * MJ_HUFF_KEY_BYTES], key, klen);
+                pp.key_len.push_back(klen);
+            }
+            global[k] = (uint32_t) si;
+        }
+        const int i0 = (int) ((int64_t) n * t / n_thr), i1 = (int) ((int64_t) n * (t + 1) / n_thr);
+        size_t d = 0;
+        for (int i = i0; i < i1; i++) {
+            if (d < sh.deferred.size() && sh.deferred[d] == i) {
+                d++;
+                continue;
+            }
+            pp.img[i].set = global[pp.img[i].set];
+        }
+    }
+    for (int t = 0; t < n_thr; t++) {
+        for (int i : share[(size_t) t].deferred) {
+            if (prepare_file(pp, pp.img[i], (size_t) i, bufs[i], lens[i], nullptr, &pp, msg, sizeof msg) != 0) {
+                return set_err("%s: image %d: %s", who, i, msg);
+            }
+        }
     }
     return choose_for_batch(pp, who);
 }

@@ -192,6 +192,13 @@ typedef struct {
 static _Thread_local FlatCacheEntry *flat_cache;   /* MJ_FLAT_CACHE entries, allocated on first use */
 static _Thread_local unsigned flat_cache_next;
 
+/* a thread that will flatten no more tables gives its cache back */
+void mj_flatten_thread_done(void) {
+    free(flat_cache);
+    flat_cache = NULL;
+    flat_cache_next = 0;
+}
+
 void mj_flatten_huff(const HuffTable *ht, int is_ac, MjHuffDev *out, MjHuffWalk *walk, MjHuffRun *pair, MjHuffPair *next) {
     uint8_t len[16], syms[256];
     int nsym = 0, keyed = 1;

@@ -41,6 +41,8 @@ int mj_parse_next_scan(const uint8_t *buf, size_t len, size_t from, MjParsed *p,
 
 /* huff_table.h:9-14 -> lookup form. */
 void mj_flatten_huff(const HuffTable *ht, int is_ac, MjHuffDev *out, MjHuffWalk *walk, MjHuffRun *pair, MjHuffPair *next);
+/* frees the calling thread's cache of flattened tables (threads that end call it) */
+void mj_flatten_thread_done(void);
 
 /* What the Huffman set of the scan depends on, as at most MJ_HUFF_KEY_BYTES bytes (returns
  * how many): images with equal keys share one set, and only the first needs it built. */

@@ -638,6 +638,44 @@ def test_batch_large_enough_for_the_longest_lanes(ctx, oracle):
     b.close()
 
 
+def test_many_files_in_one_call_are_prepared_by_several_threads(ctx, oracle):
+    """A call of 64 files or more parses its headers and flattens its tables on several host
+    threads (each with the table sets it meets, merged by key; files coded in one scan per
+    component last, by the caller's thread).  140 small files -- Annex K tables, tables fitted
+    to the image, grey, two of them coded in one scan per component, in no order -- decode as
+    the restatement says; with two damaged files among them the call is refused and the
+    message names the first."""
+    files = []
+    for i in range(140):
+        w, h = 48 + 8 * (i % 7), 40 + 8 * (i % 5)
+        grey = (i % 11) == 3
+        samp = "4:4:4" if grey else ("4:2:0", "4:2:2", "4:4:4")[i % 3]
+        img = J.synth.synth_image(w, h, 3000 + i, grey=grey)
+        if i in (37, 101):
+            files.append(J.synth.encode_jpeg(img, "4:2:0", 80, 0, scans_per_component=True))
+        else:
+            files.append(J.synth.encode_jpeg(img, samp, 50 + (i % 5) * 10, (i % 4) * 3, optimise=bool(i % 2)))
+    b = ctx.batch(files, 0)
+    b.decode()
+    b.sync()
+    for i, data in enumerate(files):
+        o = oracle.decode(data)
+        assert b.status(i) == 0
+        assert np.array_equal(b.rgb(i), o.rgb), f"file {i}: RGB"
+        if i not in (37, 101):
+            assert np.array_equal(b.coefs(i), o.coefs), f"file {i}: coefficient blocks"
+    b.close()
+    bad = list(files)
+    bad[77] = bad[77][:2] + b"\xff\xc2" + bad[77][4:]          # not a baseline frame header where one is expected
+    bad[120] = b"\x00" * 64
+    with pytest.raises(RuntimeError, match="image 77"):
+        ctx.batch(bad, 0)
+    b = ctx.batch(files[:70], 0)                                 # the context is still usable
+    b.decode()
+    assert np.array_equal(b.rgb(5), oracle.decode(files[5]).rgb)
+    b.close()
+
+
 C5_CASES = [(mode, q, opt) for mode in ("grey", "4:2:2", "4:2:0") for q in (50, 75, 95) for opt in (False, True)]
 
 
