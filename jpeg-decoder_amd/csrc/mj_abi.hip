@@ -25,6 +25,7 @@
 #include <cstring>
 #include <chrono>
 #include <algorithm>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -453,11 +454,16 @@ int prepare(const uint8_t *const *bufs, const size_t *lens, int n, MjPrep &pp, c
     };
     {
         std::vector<std::thread> pool;
+        pool.reserve((size_t) n_thr);
         for (int t = 1; t < n_thr; t++) {
-            pool.emplace_back([&work, t]() {
-                work(t);
-                mj_flatten_thread_done();      /* the thread ends here: its table cache with it */
-            });
+            try {
+                pool.emplace_back([&work, t]() {
+                    work(t);
+                    mj_flatten_thread_done();      /* the thread ends here: its table cache with it */
+                });
+            } catch (const std::system_error &) {
+                work(t);                           /* no thread to be had: the caller's does the share */
+            }
         }
         work(0);
         for (std::thread &th : pool) th.join();
