@@ -442,10 +442,11 @@ int prepare(const uint8_t *const *bufs, const size_t *lens, int n, MjPrep &pp, c
     std::vector<Share> share((size_t) n_thr);
     auto work = [&](int t) {
         Share &sh = share[(size_t) t];
+        MjPrep &sets_of = t == 0 ? pp : sh.local;     /* the caller's thread fills the call's own list: nothing to merge */
         const int i0 = (int) ((int64_t) n * t / n_thr), i1 = (int) ((int64_t) n * (t + 1) / n_thr);
         for (int i = i0; i < i1; i++) {
             bool defer = false;
-            if (prepare_file(sh.local, pp.img[i], (size_t) i, bufs[i], lens[i], &defer, nullptr, sh.msg, sizeof sh.msg) != 0) {
+            if (prepare_file(sets_of, pp.img[i], (size_t) i, bufs[i], lens[i], &defer, nullptr, sh.msg, sizeof sh.msg) != 0) {
                 sh.bad = i;
                 return;
             }
@@ -472,7 +473,7 @@ int prepare(const uint8_t *const *bufs, const size_t *lens, int n, MjPrep &pp, c
         if (sh.bad >= 0) return set_err("%s: image %d: %s", who, sh.bad, sh.msg);
     }
     /* one list of sets: those of every share looked up by key, new ones appended */
-    for (int t = 0; t < n_thr; t++) {
+    for (int t = 1; t < n_thr; t++) {
         Share &sh = share[(size_t) t];
         std::vector<uint32_t> global(sh.local.sets.size());
         for (size_t k = 0; k < sh.local.sets.size(); k++) {
@@ -570,7 +571,7 @@ MjIdctImg idct_record(const MjImageDev &im, uint32_t first_tile) {
     return r;
 }
 
-int layout(mj_batch *b, const MjPrep &pp, uint32_t flags, bool may_span) {
+int layout(mj_batch *b, MjPrep &pp, uint32_t flags, bool may_span) {
     const std::vector<MjPrepared> &prep = pp.img;
     const int n = (int) prep.size();
     b->span_src = nullptr;
@@ -579,7 +580,7 @@ int layout(mj_batch *b, const MjPrep &pp, uint32_t flags, bool may_span) {
     b->flags = flags;
     b->img.resize(n);
     b->info.resize(n);
-    b->sets = pp.sets;
+    b->sets.swap(pp.sets);          /* taken over, not copied: a set is 70 KB and a mixed batch has a hundred */
     b->tile_img.clear();
     b->wg_img.clear();
     b->pair_grp.clear();
@@ -1007,7 +1008,7 @@ void batch_free(mj_batch *b, bool park) {
 /* lay the images out in the batch's own allocation and send them on the copy stream;
  * with `wait` the call returns when the copies are through (the caller's buffers are
  * then free) */
-int fill_own(mj_batch *b, const MjPrep &pp, uint32_t flags, bool own_stage, bool wait) {
+int fill_own(mj_batch *b, MjPrep &pp, uint32_t flags, bool own_stage, bool wait) {
     mj_ctx *ctx = b->ctx;
     const std::vector<MjPrepared> &prep = pp.img;
     if (layout(b, pp, flags, true)) return -1;
@@ -1051,7 +1052,7 @@ int check_flags(uint32_t flags, const char *who) {
     return 0;
 }
 
-int batch_build(mj_ctx *ctx, const MjPrep &prep, uint32_t flags, mj_batch **out, const char *who) {
+int batch_build(mj_ctx *ctx, MjPrep &prep, uint32_t flags, mj_batch **out, const char *who) {
     if (check_flags(flags, who)) return -1;
     HIP_TRY(hipSetDevice(ctx->device));
     mj_batch *b = batch_new(ctx);
