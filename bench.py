@@ -505,6 +505,12 @@ def main():
         ts = (time.perf_counter() - ts) / 10
         small = {"images": 64, "ms_per_step": round(1e3 * ts, 4), "MPps": round(sum(px_img[:64]) / ts / 1e6, 1),
                  "kernels_avg_ms": {k: round(ms / max(n, 1), 4) for k, (ms, n) in sb.kernel_ms().items()}}
+        ik = small["kernels_avg_ms"].get("idct_colour")
+        if ik:
+            # the roofline kernel at this size: 2 bytes per coefficient sample read + 3 bytes per pixel written
+            sbytes = 2.0 * sum(samples_of(args.workload, s) for s in seeds[:64]) + 3.0 * sum(px_img[:64])
+            small["idct_colour_GBps"] = round(sbytes / (ik * 1e-3) / 1e9, 1)
+            small["idct_colour_frac_of_hbm_peak"] = round(sbytes / (ik * 1e-3) / 1e9 / 8000.0, 4)
         sb.close()
     for bt in batches:
         bt.close()
