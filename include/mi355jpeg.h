@@ -75,6 +75,12 @@ void mj_destroy(mj_ctx *ctx);
 /* Use the caller's hipStream_t (e.g. the framework's current stream) instead of
  * the context's own.  Pass NULL to go back to the context's stream. */
 int mj_set_stream(mj_ctx *ctx, void *hip_stream);
+/* The PCI address of HIP device `device` as sysfs spells it ("0000:0d:00.0", lower case,
+ * NUL-terminated; cap >= 13): the key under /sys/bus/pci/devices/ to the NUMA node and the
+ * CPUs next to the card.  Needs no context.  No counterpart in the reference, which is one
+ * thread on one CPU (jpeg_decoder.c:29-112); a process per GPU uses it to put itself and
+ * its page-locked buffers on the GPU's side of the host before it allocates them. */
+int mj_device_pci_bus_id(int device, char *buf, size_t cap);
 
 /* Parse n baseline JPEG files with the host parsers (decode_frame_header,
  * decode_huff_tables, decode_quant_table, decode_restart_interval,
@@ -117,7 +123,7 @@ void mj_host_free(void *p);
  * its own device memory, allocated on first use and reused from then on.  *out is
  * owned by the pipeline and is recycled by the depth-th submit after it (that submit
  * waits for its decode first): read results (mj_batch_sync, mj_batch_device_rgb,
- * copies, status) before then, and do not destroy it.  bufs[i] must stay valid and
+ * copies, status) before then; mj_batch_destroy on it does nothing.  bufs[i] must stay valid and
  * unchanged until mj_batch_sync(*out) returns.  Flags as for mj_batch_create. */
 typedef struct mj_pipe mj_pipe;
 int mj_pipe_create(mj_ctx *ctx, int depth, uint32_t flags, mj_pipe **out);

@@ -22,7 +22,7 @@ KERNEL_NAMES = ["scan", "entropy", "entropy_fix", "idct_colour", "memset"]
 
 # every symbol include/mi355jpeg.h and include/mi355jpeg_compat.h declare
 ABI_SYMBOLS = [
-    "mj_last_error", "mj_create", "mj_destroy", "mj_set_stream", "mj_batch_create", "mj_batch_destroy", "mj_batch_create_scan", "mj_batch_scan_end",
+    "mj_last_error", "mj_create", "mj_destroy", "mj_set_stream", "mj_device_pci_bus_id", "mj_batch_create", "mj_batch_destroy", "mj_batch_create_scan", "mj_batch_scan_end",
     "mj_batch_decode", "mj_batch_sync", "mj_batch_size", "mj_batch_image_info", "mj_batch_status",
     "mj_batch_device_rgb", "mj_batch_device_coefs", "mj_batch_copy_rgb", "mj_batch_copy_coefs",
     "mj_batch_copy_plane", "mj_batch_kernel_ms", "mj_batch_reset_timing", "mj_batch_entropy_stats",
@@ -68,6 +68,7 @@ def load_library():
     lib.mj_destroy.argtypes = [vp]
     lib.mj_destroy.restype = None
     lib.mj_set_stream.argtypes = [vp, vp]
+    lib.mj_device_pci_bus_id.argtypes = [i32, C.c_char_p, C.c_size_t]
     lib.mj_batch_create.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), i32, u32, C.POINTER(vp)]
     lib.mj_batch_destroy.argtypes = [vp]
     lib.mj_batch_destroy.restype = None
@@ -107,17 +108,30 @@ def _check(lib, rc, what):
         raise RuntimeError(f"{what} failed ({rc}): {msg.decode() if msg else '?'}")
 
 
+def device_pci_bus_id(device):
+    """PCI address of HIP device `device` ("0000:0d:00.0"); initialises the HIP runtime."""
+    lib = load_library()
+    buf = C.create_string_buffer(32)
+    _check(lib, lib.mj_device_pci_bus_id(device, buf, len(buf)), "mj_device_pci_bus_id")
+    return buf.value.decode()
+
+
 class Context:
     """mj_ctx: one per GPU / host thread."""
 
     def __init__(self, device=0):
         self.lib = load_library()
+        self.device = device
         self.h = C.c_void_p()
         self._batches = weakref.WeakSet()      # a batch must not outlive its context
         _check(self.lib, self.lib.mj_create(device, C.byref(self.h)), "mj_create")
 
     def set_stream(self, hip_stream_ptr):
         _check(self.lib, self.lib.mj_set_stream(self.h, C.c_void_p(hip_stream_ptr)), "mj_set_stream")
+
+    def pci_bus_id(self):
+        """PCI address of the context's GPU as sysfs spells it, e.g. "0000:0d:00.0"."""
+        return device_pci_bus_id(self.device)
 
     def batch(self, files, flags=0):
         return Batch(self, files, flags)

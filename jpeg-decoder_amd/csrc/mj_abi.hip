@@ -154,6 +154,7 @@ struct mj_batch {
     uint8_t *stage = nullptr;      /* pipeline slots: own staging for pageable input (a one-shot batch uses the context's) */
     size_t stage_cap = 0;
     bool borrowed = false;         /* static batch: no device memory of its own to free */
+    bool owned_by_pipe = false;    /* a pipeline slot: only mj_pipe_destroy frees it */
     MjDeviceBatch d{};
     uint64_t coef_bytes = 0, rgb_bytes = 0, plane_bytes = 0;
     hipStream_t stream = nullptr;  /* the stream the last decode was enqueued on */
@@ -674,6 +675,7 @@ int layout(mj_batch *b, MjPrep &pp, uint32_t flags, bool may_span) {
     /* frames coded in one scan per component: the file's entry describes the frame, its RGB is
      * where the unit of component 0 (same size) has its own, and the planes are always kept */
     uint32_t comb_max_x = 0, comb_max_y = 0;
+    if (b->multi.size() > 65535) return set_err("batch too large: more than 65,535 files coded in several scans");
     for (const MjMultiScan &mm : b->multi) {
         MjCombine cb{};
         mj_image_info &inf = b->info[mm.file];
@@ -1141,6 +1143,20 @@ void mj_destroy(mj_ctx *ctx) {
     delete ctx;
 }
 
+int mj_device_pci_bus_id(int device, char *buf, size_t cap) {
+    if (!buf || cap < 13) return set_err("mj_device_pci_bus_id: bad arguments (the text needs 13 bytes)");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) {
+        (void) hipGetLastError();
+        return set_err("mj_device_pci_bus_id: no HIP device %d", device);
+    }
+    HIP_TRY(hipDeviceGetPCIBusId(buf, (int) cap, device));
+    for (char *c = buf; *c; c++) {
+        if (*c >= 'A' && *c <= 'F') *c = (char) (*c - 'A' + 'a');      /* as sysfs spells it */
+    }
+    return 0;
+}
+
 int mj_set_stream(mj_ctx *ctx, void *hip_stream) {
     if (!ctx) return set_err("mj_set_stream: null context");
     ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own;
@@ -1161,7 +1177,9 @@ void mj_host_free(void *p) {
 }
 
 void mj_batch_destroy(mj_batch *b) {
-    if (!b || b->borrowed) return;   /* the view mj_decode_static hands out belongs to the context */
+    /* the view mj_decode_static hands out belongs to the context, a batch that mj_pipe_submit
+     * returned to its pipeline, which uses the slot again */
+    if (!b || b->borrowed || b->owned_by_pipe) return;
     (void) hipSetDevice(b->ctx->device);
     /* the stream every decode of this batch went to, whatever the context's current one is */
     (void) batch_wait(b);
@@ -1172,6 +1190,7 @@ void mj_batch_destroy(mj_batch *b) {
 int mj_batch_create(mj_ctx *ctx, const uint8_t *const *bufs, const size_t *lens, int n, uint32_t flags,
                     mj_batch **out) {
     if (!ctx || !bufs || !lens || !out || n <= 0) return set_err("mj_batch_create: bad arguments");
+    HIP_TRY(hipSetDevice(ctx->device));      /* the cut of the lanes follows this device's size */
     MjPrep prep;
     if (prepare(bufs, lens, n, prep, "mj_batch_create")) return -1;
     return batch_build(ctx, prep, flags, out, "mj_batch_create");
@@ -1181,6 +1200,7 @@ int mj_batch_create_scan(mj_ctx *ctx, const uint8_t *entropy, size_t entropy_len
                          const ScanHeader *sh, const HuffTables *hts, const QuantTables *qts, RestartInterval ri,
                          uint32_t flags, mj_batch **out) {
     if (!ctx || !entropy || !fh || !sh || !hts || !qts || !out) return set_err("mj_batch_create_scan: bad arguments");
+    HIP_TRY(hipSetDevice(ctx->device));
     MjParsed P;
     memset(&P, 0, sizeof P);
     P.fh = *fh;   /* shallow views: nothing here is freed through P */
@@ -1229,6 +1249,7 @@ int mj_pipe_create(mj_ctx *ctx, int depth, uint32_t flags, mj_pipe **out) {
             delete p;
             return -1;
         }
+        b->owned_by_pipe = true;
         p->slots.push_back(b);
     }
     if (hipStreamCreateWithFlags(&p->alt, hipStreamNonBlocking) != hipSuccess) {

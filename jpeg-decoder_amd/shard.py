@@ -57,3 +57,18 @@ def reduce_run(pixels: float, images: float, comp_bytes: float, mismatches: floa
     s = sums.tolist()
     m = maxs.tolist()
     return RunTotals(s[0], s[1], s[2], s[3], m[0], m[1:])
+
+
+def gather_ranks(values: Sequence[float], device=None) -> List[List[float]]:
+    """Every rank's vector of per-rank figures, in rank order: result[r][k] is values[k] of
+    rank r.  One all-gather of len(values) doubles (no pixel or coefficient data).  Without
+    an initialised process group this is [values]."""
+    import torch
+    import torch.distributed as dist
+
+    mine = torch.tensor(list(values), dtype=torch.float64, device=device)
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return [mine.tolist()]
+    out = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [t.tolist() for t in out]

@@ -1,0 +1,40 @@
+"""GPU: the benchmark's contract on one GPU, at a small size: the headline value is the
+pinned-host figure, the rank bound itself to CPUs before it allocated page-locked memory, the
+per-rank arrays, the sustained leg, and where the traffic figure comes from."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bench_line_on_one_gpu():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "C1", "--batch", "16", "--steps", "4",
+                        "--warmup", "2", "--sustain-seconds", "0.5", "--no-cpu-baseline", "--no-singles", "--gen-workers", "2"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    # the headline is the page-locked-host -> HBM rate; the resident rate has its own object
+    assert out["value"] == out["pinned_host_to_hbm"]["value"] and out["ms_per_step"] == out["pinned_host_to_hbm"]["ms_per_step"]
+    assert out["resident"]["value"] > 0 and out["roofline"]["measured_in"] == "resident region"
+    assert out["parity_mismatches_all_ranks"] == 0 and out["parity"]["images_checked"] == 16
+    # placement: from the PCI address the library reports, applied before the first page-locked buffer
+    p0 = out["host"]["placement_rank0"]
+    assert p0["source"].startswith("pci") and p0["applied"] and p0["bdf"] and p0["n_cpus"] >= 1
+    assert out["affinity_before_pinned_alloc_per_rank"] == [1]
+    assert len(out["numa_node_per_rank"]) == 1 and out["images_per_rank"] == [16]
+    for k in ("pinned_MPps_per_rank", "resident_MPps_per_rank", "h2d_GBps_per_rank", "sustained_MPps_per_rank"):
+        assert len(out[k]) == 1 and out[k][0] > 0, k
+    assert abs(out["pinned_MPps_per_rank"][0] - out["value"]) <= 0.02 * out["value"]
+    s = out["sustained"]
+    assert s["seconds"] >= 0.5 and s["submits"] >= 3 and s["MPps"] > 0 and 0.2 < s["ratio_to_value"] < 5
+    # a traffic figure only with its provenance; C1 x 16 has no counter pass on file
+    assert out["roofline"]["traffic"] is None and "why_null" in out["roofline"]["traffic_source"]

@@ -133,3 +133,19 @@ def test_unknown_flag_bits_are_refused(ctx):
         ctx.batch([data], 0x10000)
     with pytest.raises(RuntimeError, match="unknown flag"):
         ctx.pipe(2, 0x40)
+
+
+def test_destroying_a_pipeline_batch_does_nothing(ctx):
+    """A batch that mj_pipe_submit returned belongs to its pipeline: mj_batch_destroy leaves it
+    alone, and the slot is good for the next submits and for mj_pipe_destroy."""
+    data, g = load_fixture("c420_q85_100x75_ri3")
+    pipe = ctx.pipe(2, 0)
+    b = pipe.submit([data])
+    b.sync()
+    ctx.lib.mj_batch_destroy(b.h)                 # ignored
+    assert np.array_equal(b.rgb(0), g["rgb"])     # still there
+    for _ in range(4):                            # both slots used again, twice
+        b = pipe.submit([data, data])
+        assert np.array_equal(b.coefs(1), g["coefs"]) and np.array_equal(b.rgb(1), g["rgb"])
+        ctx.lib.mj_batch_destroy(b.h)
+    pipe.close()

@@ -44,9 +44,19 @@ def test_static_entry_equals_allocating_entry_twice(flags):
     small = [load_fixture("c420_q85_100x75_ri3")[0], J.synth.encode_jpeg(J.synth.synth_image(200, 120, 9), "4:4:4", 80, 0)]
     coefs_t = torch.full((40 << 20,), 0x5A5A, dtype=torch.int16, device="cuda:0")      # 80 MiB, stale contents
     rgb_t = torch.full((64 << 20,), 0xA5, dtype=torch.uint8, device="cuda:0")
+    free_after_first = None
     for files in (big, small, big):
         want = _expected(ctx, files, flags)
         got = _run_static(ctx, files, flags, coefs_t, rgb_t)
+        if free_after_first is not None:
+            # the call allocates no device memory: after the first call (which may still make the
+            # runtime load code) the free memory of the device is the same before and after
+            torch.cuda.synchronize()
+            free0 = torch.cuda.mem_get_info(0)[0]
+            view = ctx.decode_static(files, coefs_t.data_ptr(), coefs_t.numel() * 2, rgb_t.data_ptr(), rgb_t.numel(), flags)
+            view.sync()
+            assert torch.cuda.mem_get_info(0)[0] == free0, "mj_decode_static changed the device's free memory"
+        free_after_first = True
         for i, ((wc, wr, _), (gc, gr, st)) in enumerate(zip(want, got)):
             assert st == 0, i
             assert np.array_equal(gc, wc), f"image {i}: coefficients differ"
