@@ -209,9 +209,11 @@ def cpu_baseline(files, pixels, workload, cpus, seconds=10.0):
 
 def _digest_worker(args):
     """(sha256 of coefficients, sha256 of RGB, checker that produced them).  The compiled
-    reference decodes in a child of its own: on some streams with restart markers it reads
-    a partly consumed FF byte as a marker (bitstream.c:84-176), walks into the marker bytes
-    and dies; the CPU restatement then stands in for that file."""
+    reference decodes in a child of its own: where a restart marker follows a partly consumed
+    data FF (FF 00 FF Dn) it takes the FF for the marker, lands on the marker bytes and dies
+    (bitstream.c:84-151).  The CPU restatement then stands in for that file -- as
+    "reference_prefix" when every block the reference's coefficient tap recorded before it
+    died (in memory shared with the child) equals the restatement's, else as "port"."""
     kind, data = args
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from refbind import Oracle, Ref
@@ -223,7 +225,14 @@ def _digest_worker(args):
         got = _in_child(lambda: digests(Ref()))
         if got is not None:
             return got[0], got[1], "reference"
-    return digests(Oracle()) + ("port",)
+    want = Oracle().decode(data)
+    by = "port"
+    if kind == "reference":
+        t = Ref().decode_traced(data, want.coefs.shape[0], 1)
+        n = t.coefs.shape[0]
+        if t.signal and 0 < n <= want.coefs.shape[0] and (t.coefs == want.coefs[:n]).all():
+            by = "reference_prefix"
+    return hashlib.sha256(want.coefs.tobytes()).hexdigest(), hashlib.sha256(want.rgb.tobytes()).hexdigest(), by
 
 
 def checker_digests(files, workers, workload):
@@ -599,8 +608,9 @@ def main():
         mismatched += bad_c + bad_r
         parity = {"checker": checker, "images_checked": len(digests), "checked_by": checked_by(digests),
                   "images_with_coefficient_mismatch": bad_c, "images_with_rgb_mismatch": bad_r,
-                  "how": "SHA-256 of every image's coefficient blocks and RGB; the CPU restatement stands in for "
-                         "files on which the compiled reference dies"}
+                  "how": "SHA-256 of every image's coefficient blocks and RGB; the CPU restatement stands in for files on "
+                         "which the compiled reference dies (reference_prefix: the blocks it tapped before it died "
+                         "equal the restatement's)"}
     singles = None
     if rank == 0 and not args.no_singles:
         # latency of small work: one image alone (nothing to overlap its kernels with)

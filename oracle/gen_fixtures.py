@@ -10,6 +10,8 @@ Each fixture is data: ``<name>.jpg`` (the input) and ``<name>.npz`` holding what
 reference produced for it -- ``coefs`` (Huffman-decoded blocks, zigzag order, scan
 order, DC prediction applied), ``plane0..2`` (padded component planes) and ``rgb``.
 ``manifest.json`` lists them with the encoder settings and SHA-256 digests.
+Fixtures marked ``fatal`` are files the compiled reference dies on: they hold what it did
+up to that point (``--only-fatal`` regenerates just those).
 """
 import hashlib
 import io
@@ -167,6 +169,44 @@ DIVERGENT = [
 ]
 
 
+# Files on which the compiled reference dies (no outputs to keep but what it did before): the
+# restart check reads a partly consumed data FF before a restart marker (FF 00 FF Dn) as the
+# marker itself, skips only the stuffed pair and decodes the marker's bytes as data
+# (bitstream.c:84-134, :142-151; decode.c:579-584).  Made with the repository's own generator,
+# like the benchmark's inputs: (name, width, height, seed, sampling, quality, restart interval).
+FATAL = [
+    ("c444_q85_32x16_ri4_reffatal", 32, 16, 24, "4:4:4", 85, 4),
+]
+
+
+def make_fatal(ref, manifest):
+    """<name>.jpg + <name>.npz {coefs: the blocks the reference's tap saw before the process
+    died, checks: its restart checks (refbind.CHECK_DTYPE), rgb: empty}."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    import jpeg_decoder_amd as J
+    for name, w, h, seed, samp, q, ri in FATAL:
+        data = J.synth.encode_jpeg(J.synth.synth_image(w, h, seed), samp, q, ri)
+        t = ref.decode_traced(data, 4096, 4096)
+        assert t.signal != 0 and not t.finished, "the reference got through this file"
+        last = t.checks[-1]
+        with open(os.path.join(OUT, name + ".jpg"), "wb") as f:
+            f.write(data)
+        rgb = np.zeros((0, 0, 3), np.uint8)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), coefs=t.coefs, checks=t.checks, rgb=rgb)
+        manifest["fixtures"] = [f for f in manifest["fixtures"] if f["name"] != name]
+        manifest["fixtures"].append({
+            "name": name, "mode": "RGB", "X": w, "Y": h, "ncs": 3, "hsf": [1, 1, 1], "vsf": [1, 1, 1],
+            "encoder": {"generator": "jpeg-decoder_amd/synth (synth_image + encode_jpeg)", "seed": seed, "sampling": samp,
+                        "quality": q, "restart_interval": ri},
+            "jpeg_bytes": len(data), "ref_blocks": int(t.coefs.shape[0]), "divergent": True, "fatal": True,
+            "ref_signal": int(t.signal), "fatal_mcu": int(len(t.checks) - 1), "fatal_pos": int(last["pos"]),
+            "fatal_bits_consumed": int(last["off"]), "fatal_bytes": data[int(last["pos"]):int(last["pos"]) + 4].hex(),
+            "sha256_coefs": sha(t.coefs), "sha256_rgb": sha(rgb),
+        })
+        print(f"{name:32s} {len(data):7d} B  blocks before the reference died={t.coefs.shape[0]} signal={t.signal} "
+              f"MCU {len(t.checks) - 1} at byte {int(last['pos'])}")
+
+
 def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
@@ -174,6 +214,13 @@ def sha(a):
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = Ref()
+    if "--only-fatal" in sys.argv:          # add these to the manifest as it is (no Pillow needed)
+        with open(os.path.join(OUT, "manifest.json")) as f:
+            manifest = json.load(f)
+        make_fatal(ref, manifest)
+        with open(os.path.join(OUT, "manifest.json"), "w") as f:
+            json.dump(manifest, f, indent=1)
+        return
     manifest = {"generator": "oracle/gen_fixtures.py", "pillow": Image.__version__, "fixtures": []}
     for group, divergent in ((FIXTURES, False), (DIVERGENT, True)):
         for name, make, mode, kw, *post in group:
@@ -200,6 +247,7 @@ def main():
                 "sha256_coefs": sha(d.coefs), "sha256_rgb": sha(d.rgb),
             })
             print(f"{name:32s} {len(data):7d} B  blocks={d.coefs.shape[0]}")
+    make_fatal(ref, manifest)
     with open(os.path.join(OUT, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1)
 

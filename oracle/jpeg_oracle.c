@@ -508,8 +508,10 @@ static void orc_planes(const OJpeg *j, const int16_t *coefs, uint8_t **plane) {
 /* ------------------------------------------------------------------------ */
 /* colour_conversion.c:76-79: "(v < 0) ? 0 : (v > 256 ? 256 : v)" stored to a
  * uint8_t.  gcc 11.4 -O2 folds the out-of-range constant arm to 255 and converts
- * the in-range arm through a 32-bit truncation (so exactly 256.0f would wrap to 0;
- * the exhaustive sweep in the tests shows no (Y,Cb,Cr) reaches it). */
+ * the in-range arm through a 32-bit truncation, so exactly 256.0f wraps to 0.  One
+ * triple of the 2^24 reaches it: (Y, Cb, Cr) = (219, 228, 28), whose green sum rounds
+ * to 256.0f and is stored as 0 (the sweep over all triples against the compiled
+ * reference, tests/test_oracle_vs_ref.py, covers it). */
 static uint8_t ostore(float v) {
     if (v < 0.0f) return 0;
     if (v > 256.0f) return 255;

@@ -17,6 +17,7 @@
 #include <string.h>
 #include <time.h>
 
+#include "bitstream.h"
 #include "colour_conversion.h"
 #include "dct.h"
 #include "decode.h"
@@ -27,10 +28,14 @@
 static int16_t *g_tap = NULL;
 static size_t g_tap_blocks = 0, g_tap_cap = 0;
 static int g_tap_on = 0;
+static void (*g_trace_hook)(const int16_t *du) = NULL;   /* set while ref_decode_traced runs */
 
 int32_t __real_dequant_data_unit(QuantTable *qt, int16_t *du);
 
+int32_t __wrap_dequant_data_unit(QuantTable *qt, int16_t *du);
+
 int32_t __wrap_dequant_data_unit(QuantTable *qt, int16_t *du) {
+    if (g_trace_hook) g_trace_hook(du);
     if (g_tap_on) {
         if (g_tap_blocks == g_tap_cap) {
             g_tap_cap = g_tap_cap ? g_tap_cap * 2 : 4096;
@@ -40,6 +45,104 @@ int32_t __wrap_dequant_data_unit(QuantTable *qt, int16_t *du) {
         g_tap_blocks++;
     }
     return __real_dequant_data_unit(qt, du);
+}
+
+/* ---- trace into memory the caller shares with this process -----------------
+ * The reference walks off its buffers on some streams (bitstream.c:84-176) and the
+ * process dies with it.  ref_decode_traced() therefore records into a buffer the
+ * caller maps MAP_SHARED before it forks: every block the coefficient tap sees, and
+ * for every MCU the restart check's view of the stream (check_marker, decode.c:579;
+ * next_byte_restart_marker, decode.c:583; both wrapped at link time like the tap).
+ * The parent reads what was recorded up to the moment the child died. */
+typedef struct {
+    int64_t pos;          /* cursor at the call: byte offset into the file, */
+    int32_t off;          /* and bits of that byte already consumed */
+    int32_t ret;          /* what check_marker returned: 0 none, 1 restart, 2 end */
+    int64_t blocks;       /* blocks tapped before this MCU */
+    int64_t pos_after;    /* cursor after next_byte_restart_marker, -1 if it was not called */
+} RefCheck;
+
+typedef struct {
+    int64_t cap_blocks, cap_checks;    /* set by the caller */
+    volatile int64_t n_blocks, n_checks;
+    volatile int64_t finished, rc;     /* decode_jpeg_buffer came back, and with what */
+    /* int16_t coefs[cap_blocks * 64]; RefCheck checks[cap_checks]; */
+} RefTrace;
+
+static RefTrace *g_trace = NULL;
+static const uint8_t *g_trace_base = NULL;
+
+static int16_t *trace_coefs(RefTrace *t) {
+    return (int16_t *) (t + 1);
+}
+
+static RefCheck *trace_checks(RefTrace *t) {
+    return (RefCheck *) (trace_coefs(t) + t->cap_blocks * 64);
+}
+
+static void trace_block(const int16_t *du) {
+    RefTrace *t = g_trace;
+    if (t && t->n_blocks < t->cap_blocks) {
+        memcpy(trace_coefs(t) + t->n_blocks * 64, du, 64 * sizeof(int16_t));
+        t->n_blocks++;
+    }
+}
+
+uint8_t __real_check_marker(Bitstream *bs);
+int __real_next_byte_restart_marker(Bitstream *bs);
+
+uint8_t __wrap_check_marker(Bitstream *bs) {
+    uint8_t ret = __real_check_marker(bs);
+    RefTrace *t = g_trace;
+    if (t && t->n_checks < t->cap_checks) {
+        RefCheck *c = trace_checks(t) + t->n_checks;
+        c->pos = (int64_t) (bs->encoded_data - g_trace_base);
+        c->off = bs->offset;
+        c->ret = ret;
+        c->blocks = t->n_blocks;
+        c->pos_after = -1;
+        t->n_checks++;
+    }
+    return ret;
+}
+
+int __wrap_next_byte_restart_marker(Bitstream *bs) {
+    int r = __real_next_byte_restart_marker(bs);
+    RefTrace *t = g_trace;
+    if (t && t->n_checks > 0 && t->n_checks <= t->cap_checks) {
+        trace_checks(t)[t->n_checks - 1].pos_after = (int64_t) (bs->encoded_data - g_trace_base);
+    }
+    return r;
+}
+
+/* bytes the caller must map for the given capacities */
+size_t ref_trace_bytes(int64_t cap_blocks, int64_t cap_checks) {
+    return sizeof(RefTrace) + (size_t) cap_blocks * 64 * sizeof(int16_t) + (size_t) cap_checks * sizeof(RefCheck);
+}
+
+/* decode_jpeg_buffer with the trace on; may not return.  `shared` starts with a RefTrace
+ * whose cap_* fields are set and whose other fields are zero. */
+int ref_decode_traced(const uint8_t *buf, size_t len, void *shared) {
+    uint8_t *copy = (uint8_t *) calloc(len + 64, 1);
+    memcpy(copy, buf, len);
+    g_trace = (RefTrace *) shared;
+    g_trace_base = copy;
+    g_trace_hook = trace_block;
+    Image *img = NULL;
+    FrameHeader fh;
+    memset(&fh, 0, sizeof fh);
+    fh.process = -1;
+    int rc = decode_jpeg_buffer(copy, len, &fh, &img);
+    g_trace->rc = rc;
+    g_trace->finished = 1;
+    g_trace = NULL;
+    g_trace_hook = NULL;
+    if (rc == 0 && img) {
+        free_img(img);
+        free_frame_header(&fh);
+    }
+    free(copy);
+    return rc;
 }
 
 /* ---- result object ------------------------------------------------------ */

@@ -114,9 +114,57 @@ class _Lib:
         return out[: 3 * n].reshape(n, 3)
 
 
+CHECK_DTYPE = np.dtype([("pos", "<i8"), ("off", "<i4"), ("ret", "<i4"), ("blocks", "<i8"), ("pos_after", "<i8")])
+
+
+@dataclass
+class Traced:
+    """What the compiled reference did in a child process of its own, read from memory shared
+    with it: complete even when the child died."""
+    signal: int            # the signal that ended the child, 0 if it exited
+    exit_code: int         # its exit status (when signal == 0)
+    finished: bool         # decode_jpeg_buffer returned
+    rc: int                # ... with this value
+    coefs: np.ndarray      # (n, 64) int16: every block the coefficient tap saw, zigzag order
+    checks: np.ndarray     # CHECK_DTYPE, one record per MCU: cursor at check_marker, its answer, blocks tapped before,
+                           # cursor after next_byte_restart_marker (-1: not called)
+
+
 class Ref(_Lib):
     prefix = "ref"
     path = os.path.join(HERE, "_ref", "libjpegref.so")
+
+    def decode_traced(self, data: bytes, cap_blocks: int, cap_checks: int) -> Traced:
+        """decode_jpeg_buffer in a forked child with the coefficient tap and the restart
+        checks recorded in a MAP_SHARED buffer (ref_harness.c: ref_decode_traced)."""
+        import mmap
+        self.lib.ref_trace_bytes.restype = C.c_size_t
+        self.lib.ref_trace_bytes.argtypes = [C.c_int64, C.c_int64]
+        self.lib.ref_decode_traced.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p]
+        nbytes = self.lib.ref_trace_bytes(cap_blocks, cap_checks)
+        shm = mmap.mmap(-1, nbytes)                      # anonymous and shared: survives the child
+        head = np.frombuffer(shm, np.int64, 6)
+        head[0], head[1] = cap_blocks, cap_checks
+        addr = C.addressof(C.c_char.from_buffer(shm))
+        pid = os.fork()
+        if pid == 0:
+            code = 1
+            try:
+                import faulthandler
+                faulthandler.disable()            # the death of this child is the expected outcome, not news
+                devnull = os.open(os.devnull, os.O_WRONLY)
+                os.dup2(devnull, 1)
+                os.dup2(devnull, 2)
+                code = 0 if self.lib.ref_decode_traced(data, len(data), addr) == 0 else 2
+            finally:
+                os._exit(code)
+        _, status = os.waitpid(pid, 0)
+        n_blocks, n_checks, finished, rc = (int(v) for v in head[2:6])
+        coefs = np.frombuffer(shm, np.int16, n_blocks * 64, 48).reshape(n_blocks, 64).copy()
+        checks = np.frombuffer(shm, CHECK_DTYPE, n_checks, 48 + cap_blocks * 128).copy()
+        del head
+        return Traced(os.WTERMSIG(status) if os.WIFSIGNALED(status) else 0,
+                      os.WEXITSTATUS(status) if os.WIFEXITED(status) else -1, bool(finished), rc, coefs, checks)
 
 
 class Oracle(_Lib):

@@ -29,7 +29,8 @@ def load_fixture(name):
 
 
 PARITY_FIXTURES = [f["name"] for f in load_manifest() if not f["divergent"]]
-ALL_FIXTURES = [f["name"] for f in load_manifest()]
+ALL_FIXTURES = [f["name"] for f in load_manifest() if not f.get("fatal")]
+FATAL_FIXTURES = [f["name"] for f in load_manifest() if f.get("fatal")]     # the compiled reference dies on these
 
 
 @pytest.fixture(scope="session")

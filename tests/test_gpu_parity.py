@@ -83,6 +83,25 @@ def test_last_mcu_divergence_is_decoded_by_count(ctx, oracle):
     b.close()
 
 
+def test_file_the_reference_dies_on_is_decoded_whole(ctx, oracle):
+    """A partly consumed data FF before a restart marker (FF 00 FF Dn) sends the reference's
+    cursor onto the marker and the process to its end (bitstream.c:84-151).  Here markers are
+    found by the byte classifier: the whole file decodes, equal to the restatement, and the
+    blocks the reference tapped before it died are a prefix of it."""
+    from conftest import FATAL_FIXTURES
+    assert FATAL_FIXTURES
+    for name in FATAL_FIXTURES:
+        d, g = load_fixture(name)
+        b = ctx.batch([d], 0)
+        b.decode()
+        o = oracle.decode(d)
+        assert b.status(0) == 0
+        assert np.array_equal(b.coefs(0), o.coefs)
+        assert np.array_equal(b.coefs(0)[:g["coefs"].shape[0]], g["coefs"])
+        assert np.array_equal(b.rgb(0), o.rgb)
+        b.close()
+
+
 SYNTH_CASES = [
     # (w, h, sampling, quality, restart interval in MCUs, grey)
     (200, 120, "4:2:0", 85, 0, False),

@@ -10,7 +10,7 @@ import pytest
 
 import jpeg_decoder_amd as J
 from jpeg_decoder_amd import binding
-from conftest import ALL_FIXTURES, PARITY_FIXTURES, ROOT, load_fixture
+from conftest import ALL_FIXTURES, FATAL_FIXTURES, PARITY_FIXTURES, ROOT, load_fixture
 
 
 def test_library_exports_every_declared_symbol():
@@ -55,7 +55,7 @@ def test_dropin_entry_fails_loudly_without_gpu():
     assert not img.value
 
 
-@pytest.mark.parametrize("name", ALL_FIXTURES)
+@pytest.mark.parametrize("name", ALL_FIXTURES + FATAL_FIXTURES)
 @pytest.mark.parametrize("sub_bits,lane_subs", [(0, 0), (32, 1), (32, 3), (96, 2), (64, 8), (1024, 1), (512, 4)])
 def test_entropy_algorithm_emulated(name, sub_bits, lane_subs):
     """Host parsers + table flattening + scan/unstuff rules + subsequence

@@ -101,3 +101,33 @@ def test_one_scan_per_component_equals_the_interleaved_coding(oracle, case):
                 assert np.array_equal(m.coefs[at], i.coefs[src]), (c, bx, by)
                 at += 1
     assert at == m.coefs.shape[0]
+
+
+@pytest.mark.parametrize("name", __import__("conftest").FATAL_FIXTURES)
+def test_fatal_fixture_prefix_equals_the_restatement(oracle, name):
+    """Files the compiled reference dies on (its restart check takes a partly consumed data FF
+    before a restart marker, FF 00 FF Dn, for the marker: bitstream.c:84-134, :142-151).  The
+    committed record of what it did until then: every block it tapped equals the
+    restatement's, and the place it went wrong is the byte pattern named."""
+    from conftest import load_manifest
+    data, gold = load_fixture(name)
+    m = next(f for f in load_manifest() if f["name"] == name)
+    d = oracle.decode(data)
+    n = gold["coefs"].shape[0]
+    assert 0 < n < d.coefs.shape[0] and n == m["ref_blocks"]
+    assert np.array_equal(d.coefs[:n], gold["coefs"])
+    ck = gold["checks"]
+    last = ck[-1]
+    # the last thing the reference did: a restart check that said "restart marker" ...
+    assert last["ret"] == 1 and len(ck) - 1 == m["fatal_mcu"] and last["blocks"] == n
+    pos = int(last["pos"])
+    # ... with the cursor inside a data FF (1 to 7 bits of it consumed), its stuffed zero and the marker behind it
+    assert 1 <= last["off"] <= 7 and data[pos] == 0xFF and data[pos + 1] == 0x00 and data[pos + 2] == 0xFF
+    assert 0xD0 <= data[pos + 3] <= 0xD7 and data[pos:pos + 4].hex() == m["fatal_bytes"]
+    # ... after which its cursor stood on the marker instead of behind it
+    assert last["pos_after"] == pos + 2
+    # every earlier restart was taken from a fully consumed byte and ended behind its marker
+    for c in ck[:-1]:
+        if c["pos_after"] >= 0:
+            after = int(c["pos_after"])
+            assert data[after - 2] == 0xFF and 0xD0 <= data[after - 1] <= 0xD7

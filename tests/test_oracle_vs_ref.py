@@ -171,3 +171,47 @@ def test_tables_with_long_dc_codes_and_sixteen_bit_ac_codes(oracle, ref):
     assert np.array_equal(r2.coefs, o2.coefs) and np.array_equal(r2.rgb, o2.rgb)
     got, _ = J.Emu().decode_coefs(data, o.coefs.shape[0] + 16, 0, 0)
     assert np.array_equal(got[:o.coefs.shape[0]], o.coefs)
+
+
+def _assert_dies_on_partly_consumed_ff(ref, oracle, data, cap_blocks):
+    import signal
+    t = ref.decode_traced(data, cap_blocks, cap_blocks)
+    assert t.signal == signal.SIGSEGV and not t.finished
+    want = oracle.decode(data, want_rgb=False).coefs
+    n = t.coefs.shape[0]
+    # every block the reference produced before it died equals the restatement's
+    assert 0 < n < want.shape[0] and np.array_equal(t.coefs, want[:n])
+    last = t.checks[-1]
+    pos = int(last["pos"])
+    # the check that went wrong: cursor inside a data FF, then its stuffed zero, then RSTn;
+    # check_marker answers "restart" (bitstream.c:104-108) and next_byte_restart_marker skips
+    # the stuffed pair only (bitstream.c:144-151), leaving the cursor on the marker
+    assert last["ret"] == 1 and 1 <= last["off"] <= 7 and last["blocks"] == n
+    assert data[pos] == 0xFF and data[pos + 1] == 0 and data[pos + 2] == 0xFF and 0xD0 <= data[pos + 3] <= 0xD7
+    assert last["pos_after"] == pos + 2
+    # no such pattern before that point: the earlier restarts all ended behind their markers
+    for c in t.checks[:-1]:
+        if c["pos_after"] >= 0:
+            after = int(c["pos_after"])
+            assert data[after - 2] == 0xFF and 0xD0 <= data[after - 1] <= 0xD7
+    return t
+
+
+@pytest.mark.parametrize("name", __import__("conftest").FATAL_FIXTURES)
+def test_reference_dies_on_fatal_fixture_as_recorded(ref, oracle, name):
+    """The committed record (tests/golden/<name>.npz) is what this build of the reference does:
+    it is ended by a signal, and its coefficient tap and restart checks up to then are the
+    ones on file."""
+    data, gold = load_fixture(name)
+    t = _assert_dies_on_partly_consumed_ff(ref, oracle, data, 4096)
+    assert np.array_equal(t.coefs, gold["coefs"])
+    assert t.checks.tobytes() == gold["checks"].tobytes()
+
+
+def test_reference_dies_the_same_way_on_a_config2_file(ref, oracle):
+    """BASELINE config 2 (1920x1080 4:4:4, one restart interval per MCU row): about a fifth of
+    the generated files hold the pattern.  Seed 1001: 43,200 of 97,200 blocks before the end."""
+    import jpeg_decoder_amd as J
+    data = J.synth.config_jpeg("C2", 1001)
+    t = _assert_dies_on_partly_consumed_ff(ref, oracle, data, 100000)
+    assert t.coefs.shape[0] == 43200 and len(t.checks) == 14401
