@@ -157,6 +157,25 @@ int mj_pipe_host_ms(mj_pipe *p, double *wait_ms, double *work_ms, int64_t *submi
 int mj_decode_static(mj_ctx *ctx, const uint8_t *const *bufs, const size_t *lens, int n, uint32_t flags, void *dev_coefs,
                      size_t coefs_bytes, void *dev_rgb, size_t rgb_bytes, mj_batch **view);
 
+/* The upsample + colour step on its own, from planes in host memory to RGB24 in host memory:
+ * what ycbcr_rgb (colour_conversion.c:30-83; ncs = 3) and y_rgb (:5-28; ncs = 1) do with an
+ * Image.  planes[c] / strides[c] are Image.buf[c] and its row stride (the reference derives it
+ * from the frame header: the component's width padded to whole MCUs), hsf / vsf the components'
+ * sampling factors; output pixel (i, j) takes component c at row (uint32)(i * vsf/vmax), column
+ * (uint32)(j * hsf/hmax), nearest neighbour as in the reference.  Of every plane, the rows and
+ * bytes that those loops read are uploaded, no more.  Synchronous; device memory is kept in
+ * the context from call to call.  ncs = 1 reads the plane at the stride given (the reference's
+ * y_rgb strides by `width`: pass width as the stride to get that). */
+int mj_planes_to_rgb(mj_ctx *ctx, int ncs, const uint8_t *const *planes, const int32_t *strides, const int32_t *hsf,
+                     const int32_t *vsf, int width, int height, uint8_t *pixels, size_t pitch);
+
+/* decode_scan (decode.c:535-663) called on its own, outside decode_jpeg_buffer, gets a
+ * Bitstream with no length (bitstream.h:4-8) and, like the reference, trusts the stream to end
+ * in a marker.  This bounds the search for it: decode_scan fails when no marker other than
+ * RSTn follows within `bytes` of the cursor.  Default (and bytes = 0): 2^28 - 1, the largest
+ * entropy-coded segment the batch entry points accept.  Process-wide. */
+void mj_set_scan_limit(size_t bytes);
+
 /* Enqueue the whole hot path for the batch on the stream (asynchronous).  Inputs
  * are already resident in HBM; outputs (coefficients, RGB, optional planes) stay
  * in HBM.  May be called repeatedly; every call decodes from scratch. */

@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "mj_batch_decode", "mj_batch_sync", "mj_batch_size", "mj_batch_image_info", "mj_batch_status",
     "mj_batch_device_rgb", "mj_batch_device_coefs", "mj_batch_copy_rgb", "mj_batch_copy_coefs",
     "mj_batch_copy_plane", "mj_batch_kernel_ms", "mj_batch_reset_timing", "mj_batch_entropy_stats",
-    "mj_host_alloc", "mj_host_free", "mj_pipe_create", "mj_pipe_submit", "mj_pipe_destroy", "mj_pipe_host_ms", "mj_decode_static",
+    "mj_host_alloc", "mj_host_free", "mj_pipe_create", "mj_pipe_submit", "mj_pipe_destroy", "mj_pipe_host_ms", "mj_decode_static", "mj_planes_to_rgb", "mj_set_scan_limit",
 ]
 COMPAT_SYMBOLS = [
     "get_byte", "next_byte", "next_bit", "next_bit_size", "check_marker", "next_byte_restart_marker", "progress",

@@ -115,6 +115,9 @@ struct mj_ctx {
     size_t arena_cap = 0;
     uint8_t *meta_host = nullptr;
     size_t meta_cap = 0;
+    /* mj_planes_to_rgb: descriptor + planes + RGB of one frame, kept and grown from call to call */
+    uint8_t *conv = nullptr;
+    size_t conv_cap = 0;
     /* mj_decode_static: this device's copy of `scratch`, and the one batch object that lives in it */
     uint8_t *scratch_dev = nullptr;
     mj_batch *sbatch = nullptr;
@@ -698,6 +701,7 @@ int layout(mj_batch *b, MjPrep &pp, uint32_t flags, bool may_span) {
             inf.n_intervals += (int32_t) u.n_ivl;
         }
         const MjImageDev &y = b->img[mm.unit[0]];
+        cb.ncs = 3;
         cb.hmax = mm.hsf[0];
         cb.vmax = mm.vsf[0];
         cb.X = mm.X;
@@ -1140,6 +1144,7 @@ void mj_destroy(mj_ctx *ctx) {
     if (ctx->stage) (void) hipHostFree(ctx->stage);
     if (ctx->meta_host) (void) hipHostFree(ctx->meta_host);
     if (ctx->arena) (void) hipFree(ctx->arena);
+    if (ctx->conv) (void) hipFree(ctx->conv);
     delete ctx;
 }
 
@@ -1356,6 +1361,64 @@ int mj_decode_static(mj_ctx *ctx, const uint8_t *const *bufs, const size_t *lens
     /* the caller's buffers and the descriptor mirror are free once the upload is through;
      * the kernels run on */
     HIP_TRY(hipEventSynchronize(b->ev_up[0]));
+    return 0;
+}
+
+/* ---- planes -> RGB on its own (colour_conversion.c:5-83) ---------------------------- */
+
+int mj_planes_to_rgb(mj_ctx *ctx, int ncs, const uint8_t *const *planes, const int32_t *strides, const int32_t *hsf,
+                     const int32_t *vsf, int width, int height, uint8_t *pixels, size_t pitch) {
+    if (!ctx || !planes || !strides || !hsf || !vsf || !pixels) return set_err("mj_planes_to_rgb: bad arguments");
+    if (ncs != 1 && ncs != 3) return set_err("mj_planes_to_rgb: %d components (1 or 3 are converted)", ncs);
+    if (width <= 0 || height <= 0 || width > 65535 || height > 65535) return set_err("mj_planes_to_rgb: bad size %d x %d", width, height);
+    if (pitch < (size_t) 3 * (size_t) width) return set_err("mj_planes_to_rgb: pitch smaller than a row");
+    HIP_TRY(hipSetDevice(ctx->device));
+    MjCombine cb{};
+    cb.ncs = (uint32_t) ncs;
+    cb.X = (uint32_t) width;
+    cb.Y = (uint32_t) height;
+    for (int c = 0; c < ncs; c++) {
+        if (!planes[c] || strides[c] <= 0 || hsf[c] <= 0 || vsf[c] <= 0 || hsf[c] > 4 || vsf[c] > 4) {
+            return set_err("mj_planes_to_rgb: component %d: bad plane, stride or sampling factors", c);
+        }
+        cb.hmax = (uint32_t) hsf[c] > cb.hmax ? (uint32_t) hsf[c] : cb.hmax;
+        cb.vmax = (uint32_t) vsf[c] > cb.vmax ? (uint32_t) vsf[c] : cb.vmax;
+    }
+    /* what the loops of colour_conversion.c:61-69 read of every plane: rows 0 .. (uint32)((height - 1) * vratio),
+     * of the last of them the bytes up to (uint32)(hratio * (width - 1)) */
+    size_t bytes[3] = {0, 0, 0}, off = 256;
+    for (int c = 0; c < ncs; c++) {
+        const float hr = (float) hsf[c] / (float) cb.hmax, vr = (float) vsf[c] / (float) cb.vmax;
+        const uint32_t last_row = (uint32_t) ((float) (height - 1) * vr), last_col = (uint32_t) (hr * (float) (width - 1));
+        if (last_col >= (uint32_t) strides[c]) return set_err("mj_planes_to_rgb: component %d: stride %d is smaller than the row the frame needs", c, strides[c]);
+        bytes[c] = (size_t) last_row * (size_t) strides[c] + last_col + 1;
+        cb.hsf[c] = (uint32_t) hsf[c];
+        cb.vsf[c] = (uint32_t) vsf[c];
+        cb.pw[c] = (uint32_t) strides[c];
+        cb.plane_off[c] = off;
+        off = (size_t) align_up(off + bytes[c] + 4, 256);      /* + 4: the kernel reads a full-resolution row four bytes at a time */
+    }
+    cb.pitch = (uint32_t) ((3u * (uint32_t) width + 3u) & ~3u);
+    cb.rgb_off = off;
+    const size_t rgb_bytes = (size_t) cb.pitch * (size_t) height, total = off + rgb_bytes;
+    if (ctx->conv_cap < total) {
+        if (ctx->conv) (void) hipFree(ctx->conv);
+        ctx->conv = nullptr;
+        ctx->conv_cap = 0;
+        void *p = nullptr;
+        if (hipMalloc(&p, total + total / 8) != hipSuccess) return set_err("mj_planes_to_rgb: cannot allocate %zu bytes of device memory", total);
+        ctx->conv = static_cast<uint8_t *>(p);
+        ctx->conv_cap = total + total / 8;
+    }
+    if (host_reserve(&ctx->stage, &ctx->stage_cap, total, "the planes and their RGB")) return -1;
+    memcpy(ctx->stage, &cb, sizeof cb);
+    for (int c = 0; c < ncs; c++) memcpy(ctx->stage + cb.plane_off[c], planes[c], bytes[c]);
+    hipStream_t s = ctx->stream;
+    HIP_TRY(hipMemcpyAsync(ctx->conv, ctx->stage, off, hipMemcpyHostToDevice, s));
+    HIP_TRY(mj_launch_planes_rgb(reinterpret_cast<const MjCombine *>(ctx->conv), 1, cb.X, cb.Y, ctx->conv, ctx->conv, false, s));
+    HIP_TRY(hipMemcpyAsync(ctx->stage + off, ctx->conv + off, rgb_bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (int y = 0; y < height; y++) memcpy(pixels + (size_t) y * pitch, ctx->stage + off + (size_t) y * cb.pitch, (size_t) 3 * (size_t) width);
     return 0;
 }
 

@@ -141,8 +141,9 @@ typedef struct {
     uint32_t pad_;
 } MjImageDev;
 
-/* A frame coded in one scan per component: where the three planes its scans were decoded into
- * lie, and where the RGB of the file goes (the last kernel of the decode combines them). */
+/* Planes -> RGB for one frame: where its component planes lie and where its RGB goes.  Used for
+ * frames coded in one scan per component (the planes their scans were decoded into; the last
+ * kernel of the decode combines them) and for ycbcr_rgb / y_rgb on planes the caller filled. */
 typedef struct {
     uint64_t plane_off[3];   /* byte offsets in the batch plane buffer, by component */
     uint64_t rgb_off;        /* first byte in the RGB buffer */
@@ -150,7 +151,7 @@ typedef struct {
     uint32_t hsf[3], vsf[3]; /* sampling factors of the frame */
     uint32_t hmax, vmax;
     uint32_t X, Y, pitch;
-    uint32_t pad_;
+    uint32_t ncs;            /* 3, or 1: grey (R = G = B = component 0) */
 } MjCombine;
 
 /* What the IDCT + colour kernel needs to know about an image, in one 64-byte record that a

@@ -89,6 +89,8 @@ hipError_t mj_launch_entropy_write(const MjDeviceBatch &b, hipStream_t s);
 hipError_t mj_launch_entropy_serial(const MjDeviceBatch &b, hipStream_t s);
 hipError_t mj_launch_idct_colour(const MjDeviceBatch &b, hipStream_t s);
 hipError_t mj_launch_combine(const MjDeviceBatch &b, hipStream_t s);
+hipError_t mj_launch_planes_rgb(const MjCombine *comb, uint32_t n, uint32_t max_x, uint32_t max_y, const uint8_t *planes, uint8_t *rgb,
+                                bool rgba, hipStream_t s);
 
 /* Compute units of the current device (asked once per device). */
 static inline hipError_t mj_device_cus(uint32_t *out) {

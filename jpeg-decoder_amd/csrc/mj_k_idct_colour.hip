@@ -721,25 +721,71 @@ __global__ __launch_bounds__(TPB, MJ_IDCT_WAVES) void mj_k_idct_colour(MjDeviceB
 }
 
 /* ------------------------------------------------------------------------ */
-/* frames coded in one scan per component                                   */
+/* planes -> RGB                                                            */
 /* ------------------------------------------------------------------------ */
-/* Every scan of such a frame has been decoded as a grey image of the component's own size, with
- * its plane kept; this kernel is the upsample + colour step of the frame (colour_conversion.c:30-83:
- * nearest neighbour, source index = (uint32)(ratio * i) with ratio = (float) sf / max_sf) from those
- * planes into the RGB of the file.  One thread per pixel; such files are rare. */
-__global__ __launch_bounds__(256) void mj_k_combine(MjDeviceBatch b) {
-    const MjCombine &cb = b.comb[blockIdx.z];
-    const uint32_t x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    if (x >= cb.X || y >= cb.Y) return;
-    uint32_t v[3];
+/* The upsample + colour step on its own (colour_conversion.c:30-83: nearest neighbour, source
+ * index = (uint32)(ratio * i) with ratio = (float) sf / max_sf; :5-28 for one component), from
+ * planar samples to RGB.  Two callers: frames coded in one scan per component, whose scans were
+ * decoded as grey images with their planes kept, and ycbcr_rgb / y_rgb on planes the caller
+ * filled.  A lane takes four neighbouring pixels of a row and stores them as twelve (RGBA:
+ * sixteen) bytes; a component at full horizontal resolution is read four samples at a time. */
+constexpr uint32_t PLANES_TPB = 256;
+
+template <bool RGBA>
+__global__ __launch_bounds__(PLANES_TPB) void mj_k_planes_rgb(const MjCombine *comb, const uint8_t *planes, uint8_t *rgb) {
+    __shared__ MjChromaTerm s_tab[512];
+    s_tab[threadIdx.x] = c_chroma.t[threadIdx.x];
+    s_tab[256 + threadIdx.x] = c_chroma.t[256 + threadIdx.x];
+    __syncthreads();
+    const MjCombine &cb = comb[blockIdx.z];
+    const uint32_t x0 = (blockIdx.x * PLANES_TPB + threadIdx.x) * 4u, y = blockIdx.y;
+    if (x0 >= cb.X || y >= cb.Y) return;
+    const uint32_t ncs = cb.ncs;
+    uint32_t v[3][4];
 #pragma unroll
     for (int c = 0; c < 3; c++) {
+        if ((uint32_t) c >= ncs) {
+            v[c][0] = v[c][1] = v[c][2] = v[c][3] = 128u;
+            continue;
+        }
         const float hr = (float) cb.hsf[c] / (float) cb.hmax, vr = (float) cb.vsf[c] / (float) cb.vmax;
-        const uint32_t sx = (uint32_t) (hr * (float) x), sy = (uint32_t) ((float) y * vr);
-        v[c] = b.planes[cb.plane_off[c] + (uint64_t) sy * cb.pw[c] + sx];
+        const uint32_t sy = (uint32_t) ((float) y * vr);
+        const uint8_t *row = planes + cb.plane_off[c] + (uint64_t) sy * cb.pw[c];
+        if (cb.hsf[c] == cb.hmax && ((cb.plane_off[c] | cb.pw[c]) & 3u) == 0 && x0 + 4 <= cb.pw[c]) {
+            const uint32_t w = *reinterpret_cast<const uint32_t *>(row + x0);
+            v[c][0] = w & 0xFFu;
+            v[c][1] = (w >> 8) & 0xFFu;
+            v[c][2] = (w >> 16) & 0xFFu;
+            v[c][3] = w >> 24;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t x = x0 + k < cb.X ? x0 + k : cb.X - 1;
+                v[c][k] = row[(uint32_t) (hr * (float) x)];
+            }
+        }
     }
-    const uint32_t px = mj_ycc_to_rgb(v[0], v[1], v[2], c_chroma.t[v[1]], c_chroma.t[256 + v[2]]);
-    store_px(b.rgb + cb.rgb_off + (uint64_t) y * cb.pitch, x, px, b.rgba != 0);
+    uint32_t px[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        px[k] = ncs == 1 ? v[0][k] * 0x010101u : mj_ycc_to_rgb(v[0][k], v[1][k], v[2][k], s_tab[v[1][k]], s_tab[256 + v[2][k]]);
+    }
+    uint8_t *o = rgb + cb.rgb_off + (uint64_t) y * cb.pitch;
+    const bool aligned = ((cb.rgb_off | cb.pitch) & 3u) == 0;
+    if (x0 + 4 <= cb.X && (RGBA || aligned)) {
+        if (RGBA) {
+            *reinterpret_cast<uint4 *>(o + 16u * (x0 >> 2)) =
+                make_uint4(px[0] | 0xFF000000u, px[1] | 0xFF000000u, px[2] | 0xFF000000u, px[3] | 0xFF000000u);
+        } else {
+            Rgb4 w;
+            w.a = px[0] | (px[1] << 24);            /* R0 G0 B0 R1 */
+            w.b = (px[1] >> 8) | (px[2] << 16);     /* G1 B1 R2 G2 */
+            w.c = (px[2] >> 16) | (px[3] << 8);     /* B2 R3 G3 B3 */
+            *reinterpret_cast<Rgb4 *>(o + 3u * x0) = w;
+        }
+    } else {
+        for (uint32_t k = 0; k < 4 && x0 + k < cb.X; k++) store_px(o, x0 + k, px[k], RGBA);
+    }
 }
 
 }  // namespace
@@ -756,8 +802,19 @@ hipError_t mj_launch_idct_colour(const MjDeviceBatch &b, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t mj_launch_combine(const MjDeviceBatch &b, hipStream_t s) {
-    if (b.n_comb == 0) return hipSuccess;
-    hipLaunchKernelGGL(mj_k_combine, dim3((b.comb_max_x + 255) / 256, b.comb_max_y, b.n_comb), dim3(256), 0, s, b);
+hipError_t mj_launch_planes_rgb(const MjCombine *comb, uint32_t n, uint32_t max_x, uint32_t max_y, const uint8_t *planes, uint8_t *rgb,
+                                bool rgba, hipStream_t s) {
+    if (n == 0 || max_x == 0 || max_y == 0) return hipSuccess;
+    if (n > 65535u || max_y > 65535u) return hipErrorInvalidValue;      /* the grid's y and z */
+    const dim3 grid((max_x + 4 * PLANES_TPB - 1) / (4 * PLANES_TPB), max_y, n);
+    if (rgba) {
+        hipLaunchKernelGGL(mj_k_planes_rgb<true>, grid, dim3(PLANES_TPB), 0, s, comb, planes, rgb);
+    } else {
+        hipLaunchKernelGGL(mj_k_planes_rgb<false>, grid, dim3(PLANES_TPB), 0, s, comb, planes, rgb);
+    }
     return hipGetLastError();
+}
+
+hipError_t mj_launch_combine(const MjDeviceBatch &b, hipStream_t s) {
+    return mj_launch_planes_rgb(b.comb, b.n_comb, b.comb_max_x, b.comb_max_y, b.planes, b.rgb, b.rgba != 0, s);
 }

@@ -5,8 +5,9 @@
  *   decode_scan          decode.c:535-663   which here uploads the entropy-coded bytes
  *                                           and runs the HIP kernels;
  *   allocate_img/free_img decode.c:95-136
- *   ycbcr_rgb / y_rgb    colour_conversion.c:5-83   copy out the RGB the fused
- *                                           IDCT+colour kernel already produced.
+ *   ycbcr_rgb / y_rgb    colour_conversion.c:5-83   the RGB the fused IDCT+colour kernel
+ *                                           produced while the planes are as the decode
+ *                                           left them; else planes -> RGB on the GPU.
  *
  * There is no CPU decode behind these names.  If no HIP device is usable they
  * return -1 and say so on stderr.
@@ -30,9 +31,21 @@ typedef struct {
     Image *img;
     mj_batch *batch;
     size_t plane_bytes[4];
+    uint64_t plane_hash[4];    /* of the planes as the decode left them in Image.buf (valid while batch != NULL) */
 } SideEntry;
 static SideEntry *g_side = NULL;
 static size_t g_side_n = 0, g_side_cap = 0;
+
+/* How far decode_scan, called on its own, looks for the marker that ends its scan.  The default
+ * is the largest entropy-coded segment the batch entry points accept. */
+#define MJ_SCAN_LIMIT_DEFAULT (((size_t) 1 << 28) - 1)
+static size_t g_scan_limit = MJ_SCAN_LIMIT_DEFAULT;
+
+void mj_set_scan_limit(size_t bytes) {
+    pthread_mutex_lock(&g_lock);
+    g_scan_limit = bytes ? bytes : MJ_SCAN_LIMIT_DEFAULT;
+    pthread_mutex_unlock(&g_lock);
+}
 
 /* end of the caller's buffer while decode_jpeg_buffer is on the stack */
 static _Thread_local const uint8_t *t_buf_end = NULL;
@@ -76,6 +89,24 @@ static void side_drop(Image *img) {
     if (!e) return;
     if (e->batch) mj_batch_destroy(e->batch);
     *e = g_side[--g_side_n];
+}
+
+/* A quick 64-bit digest of a plane: tells whether the caller has touched the samples between
+ * the decode and the colour step (it then gets its samples converted, not the cached result). */
+static uint64_t plane_digest(const uint8_t *p, size_t n) {
+    uint64_t a = 0x9E3779B97F4A7C15ull ^ n, b = 0xC2B2AE3D27D4EB4Full;
+    size_t i = 0;
+    for (; i + 16 <= n; i += 16) {
+        uint64_t w0, w1;
+        memcpy(&w0, p + i, 8);
+        memcpy(&w1, p + i + 8, 8);
+        a = (a ^ w0) * 0x9FB21C651E98DF25ull;
+        a ^= a >> 32;
+        b = (b ^ w1) * 0xD6E8FEB86659FD93ull;
+        b ^= b >> 32;
+    }
+    for (; i < n; i++) a = (a ^ p[i]) * 0x100000001B3ull;
+    return a ^ (b * 0x9E3779B97F4A7C15ull);
 }
 
 /* ---- Image (decode.c:95-136) -------------------------------------------- */
@@ -140,11 +171,19 @@ int decode_scan(Bitstream *bs, Image *img, FrameHeader *fh, ScanHeader *sh, Huff
         if (t_buf_end <= ent) return -1;   /* the file ends with its scan header */
         ent_len = (size_t) (t_buf_end - ent);
     } else {
-        /* called on its own: like the reference, trust the stream to end in a marker */
-        const uint8_t *p = ent;
+        /* called on its own: the Bitstream carries no length (bitstream.h:4-8), so, like the
+         * reference, trust the stream to end in a marker -- but look for it no further than
+         * the limit (mj_set_scan_limit) */
+        pthread_mutex_lock(&g_lock);
+        const size_t limit = g_scan_limit;
+        pthread_mutex_unlock(&g_lock);
+        const uint8_t *p = ent, *stop = ent + limit;
         for (;;) {
-            p = (const uint8_t *) memchr(p, 0xFF, (size_t) 1 << 30);
-            if (!p) return -1;
+            p = (p < stop) ? (const uint8_t *) memchr(p, 0xFF, (size_t) (stop - p)) : NULL;
+            if (!p) {
+                fprintf(stderr, "mi355jpeg: decode_scan: no marker ends the scan within %zu bytes (mj_set_scan_limit)\n", limit);
+                return -1;
+            }
             if (p[1] != 0x00 && p[1] != 0xFF && !(p[1] >= 0xD0 && p[1] <= 0xD7)) break;
             p += 1;
         }
@@ -179,6 +218,7 @@ int decode_scan(Bitstream *bs, Image *img, FrameHeader *fh, ScanHeader *sh, Huff
             fprintf(stderr, "mi355jpeg: %s\n", mj_last_error());
             goto out;
         }
+        se->plane_hash[c] = plane_digest(img->buf[c], se->plane_bytes[c]);
     }
     size_t end_off = 0;
     if (mj_batch_scan_end(b, 0, &end_off) != 0) goto out;
@@ -231,6 +271,7 @@ static int decode_all_scans(const uint8_t *buf, size_t len, Image *img) {
             goto out;
         }
         for (size_t y = 0; y < ph; y++) memcpy(img->buf[c] + y * stride, tmp + y * pw, pw);
+        se->plane_hash[c] = plane_digest(img->buf[c], se->plane_bytes[c]);
     }
     {
         int64_t mcus = (int64_t) inf.mcus_x * inf.mcus_y;
@@ -364,41 +405,66 @@ int get_max_sf(FrameHeader *fh, uint8_t *max_hsf, uint8_t *max_vsf) {
     return 0;
 }
 
-static int copy_rgb_out(Image *img, uint8_t *pixels, uint16_t width, uint16_t height, uint16_t pitch, int want_ncs) {
-    if (!img || !pixels) return -1;
+/* The row stride the reference's colour loops give a component's plane: its width padded to
+ * whole MCUs (colour_conversion.c:46-47). */
+static size_t frame_stride(const Component *c) {
+    return pad_to_mcu(c->x, 8u * c->hsf);
+}
+
+/* Does the result the decode kept for this Image still stand for what the caller asks: the same
+ * frame geometry in `fh`, the whole frame, and planes that hold what the decode put there? */
+static int cached_rgb_is_current(const SideEntry *se, const FrameHeader *fh, const Image *img, uint16_t width, uint16_t height, int ncs) {
+    mj_image_info inf;
+    if (!se || !se->batch || mj_batch_image_info(se->batch, 0, &inf) != 0) return 0;
+    if (inf.ncs != ncs || fh->ncs != ncs || width != inf.X || height != inf.Y) return 0;
+    for (int c = 0; c < ncs; c++) {
+        if (fh->cs[c].hsf != inf.hsf[c] || fh->cs[c].vsf != inf.vsf[c]) return 0;
+        if ((size_t) img->width[c] != frame_stride(&fh->cs[c])) return 0;
+    }
+    for (int c = 0; c < ncs; c++) {
+        if (plane_digest(img->buf[c], se->plane_bytes[c]) != se->plane_hash[c]) return 0;
+    }
+    return 1;
+}
+
+/* ycbcr_rgb / y_rgb (colour_conversion.c:30-83, :5-28): the samples in Image.buf, at the strides
+ * and sampling factors `fh` gives, to RGB24 at `pitch`.  An Image that this library's decode
+ * filled and nobody has touched since gets the RGB the fused kernel made at decode time; any
+ * other (planes the caller filled or edited, an Image not made by allocate_img, another frame
+ * header, a window of the frame) goes through the planes -> RGB kernel. */
+static int colour_out(FrameHeader *fh, Image *img, uint8_t *pixels, uint16_t width, uint16_t height, uint16_t pitch, int ncs) {
+    if (!fh || !fh->cs || !img || !img->buf || !img->width || !pixels) return -1;
+    if (fh->ncs < ncs || width == 0 || height == 0) return -1;
     int rc = -1;
     pthread_mutex_lock(&g_lock);
     SideEntry *se = side_find(img);
-    mj_batch *b = se ? se->batch : NULL;
-    mj_image_info inf;
-    if (!b) {
-        fprintf(stderr, "mi355jpeg: Image was not produced by this library's decode_scan (no GPU result to convert)\n");
-    } else if (mj_batch_image_info(b, 0, &inf) == 0 && inf.ncs == want_ncs) {
-        if (width == inf.X && height == inf.Y) {
-            rc = mj_batch_copy_rgb(b, 0, pixels, pitch);
-        } else if (width <= inf.X && height <= inf.Y && (size_t) pitch >= (size_t) 3 * width) {
-            /* a caller-chosen window of the frame: copy through a full-size staging image */
-            uint8_t *tmp = (uint8_t *) malloc((size_t) 3 * inf.X * inf.Y);
-            if (tmp && mj_batch_copy_rgb(b, 0, tmp, (size_t) 3 * inf.X) == 0) {
-                for (int y = 0; y < height; y++) memcpy(pixels + (size_t) y * pitch, tmp + (size_t) y * 3 * inf.X, (size_t) 3 * width);
-                rc = 0;
-            }
-            free(tmp);
+    if (cached_rgb_is_current(se, fh, img, width, height, ncs)) {
+        rc = mj_batch_copy_rgb(se->batch, 0, pixels, pitch);
+    } else {
+        mj_ctx *ctx = default_ctx();
+        const uint8_t *planes[3] = {NULL, NULL, NULL};
+        int32_t strides[3] = {0, 0, 0}, hsf[3] = {1, 1, 1}, vsf[3] = {1, 1, 1};
+        for (int c = 0; c < ncs; c++) {
+            planes[c] = img->buf[c];
+            strides[c] = (int32_t) frame_stride(&fh->cs[c]);
+            hsf[c] = fh->cs[c].hsf;
+            vsf[c] = fh->cs[c].vsf;
         }
-        if (rc != 0) fprintf(stderr, "mi355jpeg: %s\n", mj_last_error());
+        if (ctx) rc = mj_planes_to_rgb(ctx, ncs, planes, strides, hsf, vsf, width, height, pixels, pitch);
     }
+    if (rc != 0) fprintf(stderr, "mi355jpeg: %s\n", mj_last_error());
     pthread_mutex_unlock(&g_lock);
     return rc;
 }
 
 int ycbcr_rgb(FrameHeader *fh, Image *img, uint8_t *pixels, uint16_t width, uint16_t height, uint16_t pitch) {
-    (void) fh;
-    return copy_rgb_out(img, pixels, width, height, pitch, 3);
+    return colour_out(fh, img, pixels, width, height, pitch, 3);
 }
 
+/* One component: R = G = B.  The plane is read at its own stride (the reference strides it by
+ * `width`, colour_conversion.c:20, which shears every frame whose width is not a multiple of 8). */
 int y_rgb(FrameHeader *fh, Image *img, uint8_t *pixels, uint16_t width, uint16_t height, uint16_t pitch) {
-    (void) fh;
-    return copy_rgb_out(img, pixels, width, height, pitch, 1);
+    return colour_out(fh, img, pixels, width, height, pitch, 1);
 }
 
 int yccb_rgb(FrameHeader *fh, Image *img, uint8_t *pixels, uint16_t width, uint16_t height, uint16_t pitch) {

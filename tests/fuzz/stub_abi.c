@@ -22,3 +22,8 @@ int mj_batch_image_info(const mj_batch *b, int i, mj_image_info *info) { (void) 
 int mj_batch_copy_plane(mj_batch *b, int i, int comp, uint8_t *dst) { (void) b; (void) i; (void) comp; (void) dst; return -1; }
 int mj_batch_copy_rgb(mj_batch *b, int i, uint8_t *dst, size_t dst_pitch) { (void) b; (void) i; (void) dst; (void) dst_pitch; return -1; }
 int mj_batch_scan_end(mj_batch *b, int i, size_t *offset) { (void) b; (void) i; (void) offset; return -1; }
+int mj_planes_to_rgb(mj_ctx *ctx, int ncs, const uint8_t *const *planes, const int32_t *strides, const int32_t *hsf, const int32_t *vsf,
+                     int width, int height, uint8_t *pixels, size_t pitch) {
+    (void) ctx; (void) ncs; (void) planes; (void) strides; (void) hsf; (void) vsf; (void) width; (void) height; (void) pixels; (void) pitch;
+    return -1;
+}

@@ -397,6 +397,176 @@ def test_dropin_api_on_a_file_of_one_scan_per_component(ctx, oracle):
     lib.free_frame_header(C.byref(fh))
 
 
+def _frame_of(g, hsf, vsf):
+    """_FrameHeader + component array for a golden fixture's geometry."""
+    H, W = g["rgb"].shape[:2]
+    ncs = len(hsf)
+    cs = (_Component * ncs)()
+    hm, vm = max(hsf), max(vsf)
+    for c in range(ncs):
+        cs[c].id, cs[c].hsf, cs[c].vsf, cs[c].qtid = c + 1, hsf[c], vsf[c], 0
+        cs[c].x = -(-W * hsf[c] // hm)
+        cs[c].y = -(-H * vsf[c] // vm)
+    fh = _FrameHeader()
+    fh.process, fh.precision, fh.X, fh.Y, fh.ncs = 0, 8, W, H, ncs
+    fh.cs = C.cast(cs, C.POINTER(_Component))
+    return fh, cs
+
+
+@pytest.mark.parametrize("name,hsf,vsf", [
+    ("c420_q85_100x75_ri3", (2, 1, 1), (2, 1, 1)), ("c422_q75_120x72", (2, 1, 1), (1, 1, 1)),
+    ("c444_q75_opt_57x43", (1, 1, 1), (1, 1, 1)), ("g_q95_opt_120x88_rirow", (1,), (1,)),
+    ("C1_c420_q85_512x512", (2, 1, 1), (2, 1, 1)), ("c422_q50_33x17", (2, 1, 1), (1, 1, 1))])
+def test_colour_entry_points_convert_the_planes_they_are_given(ctx, name, hsf, vsf):
+    """ycbcr_rgb / y_rgb on an Image the caller filled (allocate_img + the reference's own
+    planes from the golden file): the RGB is the reference's (colour_conversion.c:5-83), at a
+    pitch wider than a row; an Image whose planes the caller edits after a decode gets the
+    edited samples converted, not the RGB of the decode."""
+    lib = J.load_library()
+    _, g = load_fixture(name)
+    fh, cs = _frame_of(g, hsf, vsf)
+    H, W = g["rgb"].shape[:2]
+    lib.allocate_img.argtypes = [C.POINTER(_FrameHeader)]
+    lib.allocate_img.restype = C.POINTER(_Image)
+    lib.free_img.argtypes = [C.POINTER(_Image)]
+    lib.free_img.restype = None
+    fn = lib.y_rgb if len(hsf) == 1 else lib.ycbcr_rgb
+    fn.argtypes = [C.POINTER(_FrameHeader), C.POINTER(_Image), C.c_void_p, C.c_uint16, C.c_uint16, C.c_uint16]
+    img = lib.allocate_img(C.byref(fh))
+    assert img
+    for c in range(len(hsf)):
+        p = np.ascontiguousarray(g[f"plane{c}"])
+        assert img.contents.width[c] == p.shape[1]
+        C.memmove(img.contents.buf[c], p.ctypes.data, p.size)
+    pitch = 3 * W + 8
+    pixels = np.zeros((H, pitch), np.uint8)
+    assert fn(C.byref(fh), img, pixels.ctypes.data, W, H, pitch) == 0
+    assert np.array_equal(pixels[:, :3 * W].reshape(H, W, 3), g["rgb"])
+    assert not pixels[:, 3 * W:].any(), "bytes beyond the row were touched"
+    # a window of the frame: the top-left corner, as the reference's loops would produce it
+    w2, h2 = max(1, W // 2 - 1), max(1, H // 3)
+    win = np.zeros((h2, 3 * w2), np.uint8)
+    assert fn(C.byref(fh), img, win.ctypes.data, w2, h2, 3 * w2) == 0
+    assert np.array_equal(win.reshape(h2, w2, 3), g["rgb"][:h2, :w2])
+    lib.free_img(img)
+
+
+def test_colour_entry_point_sees_planes_edited_after_the_decode(ctx, oracle):
+    lib = J.load_library()
+    data, g = load_fixture("c420_q85_100x75_ri3")
+    buf = C.create_string_buffer(data, len(data) + 16)
+    fh = _FrameHeader()
+    fh.process = -1
+    img = C.POINTER(_Image)()
+    lib.decode_jpeg_buffer.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(_FrameHeader), C.POINTER(C.POINTER(_Image))]
+    assert lib.decode_jpeg_buffer(buf, len(data), C.byref(fh), C.byref(img)) == 0
+    H, W = g["rgb"].shape[:2]
+    lib.ycbcr_rgb.argtypes = [C.POINTER(_FrameHeader), C.POINTER(_Image), C.c_void_p, C.c_uint16, C.c_uint16, C.c_uint16]
+    pixels = np.zeros((H, 3 * W), np.uint8)
+    assert lib.ycbcr_rgb(C.byref(fh), img, pixels.ctypes.data, W, H, 3 * W) == 0
+    assert np.array_equal(pixels.reshape(H, W, 3), g["rgb"])                   # untouched: the decode's own RGB
+    # the caller inverts the luma plane and flattens Cb: the next call converts those samples
+    planes = [np.ctypeslib.as_array(img.contents.buf[c], shape=g[f"plane{c}"].shape) for c in range(3)]
+    planes[0][:] = 255 - planes[0]
+    planes[1][:] = 77
+    cbu = np.repeat(np.repeat(planes[1], 2, 0), 2, 1)[:H, :W]
+    cru = np.repeat(np.repeat(planes[2], 2, 0), 2, 1)[:H, :W]
+    want = oracle.ycbcr_row(planes[0][:H, :W].ravel(), cbu.ravel(), cru.ravel()).reshape(H, W, 3)
+    assert lib.ycbcr_rgb(C.byref(fh), img, pixels.ctypes.data, W, H, 3 * W) == 0
+    assert np.array_equal(pixels.reshape(H, W, 3), want)
+    lib.free_img.argtypes = [C.POINTER(_Image)]
+    lib.free_img.restype = None
+    lib.free_img(img)
+    lib.free_frame_header.argtypes = [C.POINTER(_FrameHeader)]
+    lib.free_frame_header(C.byref(fh))
+
+
+class _Bitstream(C.Structure):
+    _fields_ = [("encoded_data", C.c_void_p), ("offset", C.c_uint8), ("size", C.c_uint32)]
+
+
+def _parse_up_to_sos(lib, buf, data):
+    """The marker walk of decode.c:160-341 up to the scan header, with the library's own segment
+    parsers: (fh, sh, hts, qts, ri, cursor on the first entropy-coded byte)."""
+    base = C.addressof(buf)
+    fh = _FrameHeader()
+    fh.process = -1
+    sh, hts, qts = (C.create_string_buffer(4096) for _ in range(3))     # ScanHeader, HuffTables, QuantTables: opaque here
+    ri = C.c_uint16(0)
+    bs = _Bitstream()
+    have_hts = False
+    i = 2
+    while True:
+        assert data[i] == 0xFF
+        m, n = data[i + 1], (data[i + 2] << 8) | data[i + 3]
+        bs.encoded_data, bs.offset = base + i + 2, 0
+        if m == 0xC0:
+            assert lib.decode_frame_header(0, C.byref(bs), C.byref(fh)) == 0
+        elif m == 0xC4:
+            if not have_hts:
+                lib.new_huff_tables(fh.process, hts)
+                have_hts = True
+            assert lib.decode_huff_tables(C.byref(bs), hts) == 0
+        elif m == 0xDB:
+            assert lib.decode_quant_table(C.byref(bs), qts) == 0
+        elif m == 0xDD:
+            assert lib.decode_restart_interval(C.byref(bs), C.byref(ri)) == 0
+        elif m == 0xDA:
+            assert lib.decode_scan_header(C.byref(bs), sh) == 0
+            bs.encoded_data, bs.offset = base + i + 2 + n, 0
+            return fh, sh, hts, qts, ri, bs
+        i += 2 + n
+
+
+@pytest.mark.parametrize("name", ["c420_q85_100x75_ri3", "g_q75_72x40_ri4", "c444_q75_opt_57x43"])
+def test_decode_scan_called_on_its_own(ctx, name):
+    """The inner seam (decode.c:333: decode_scan at the SOS case) with structs from the segment
+    parsers, outside decode_jpeg_buffer: planes as the reference's, the cursor left on the marker
+    that ends the scan, and the search for that marker bounded by mj_set_scan_limit."""
+    lib = J.load_library()
+    data, g = load_fixture(name)
+    buf = C.create_string_buffer(data, len(data) + 16)
+    for f in (lib.decode_frame_header, lib.decode_huff_tables, lib.decode_quant_table, lib.decode_restart_interval,
+              lib.decode_scan_header, lib.new_huff_tables, lib.decode_scan, lib.free_huff_tables):
+        f.restype = C.c_int
+    lib.decode_frame_header.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+    lib.new_huff_tables.argtypes = [C.c_int, C.c_void_p]
+    for f in (lib.decode_huff_tables, lib.decode_quant_table, lib.decode_restart_interval, lib.decode_scan_header):
+        f.argtypes = [C.c_void_p, C.c_void_p]
+    fh, sh, hts, qts, ri, bs = _parse_up_to_sos(lib, buf, data)
+    lib.allocate_img.argtypes = [C.POINTER(_FrameHeader)]
+    lib.allocate_img.restype = C.POINTER(_Image)
+    img = lib.allocate_img(C.byref(fh))
+    assert img
+    lib.decode_scan.argtypes = [C.c_void_p, C.POINTER(_Image), C.POINTER(_FrameHeader), C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint16]
+    lib.mj_set_scan_limit.argtypes = [C.c_size_t]
+    lib.mj_set_scan_limit.restype = None
+    start = bs.encoded_data
+    lib.mj_set_scan_limit(16)                      # the scan is longer than that: refused, nothing read beyond
+    assert lib.decode_scan(C.byref(bs), img, C.byref(fh), sh, hts, qts, ri.value) == -1
+    lib.mj_set_scan_limit(0)                       # back to the default
+    bs.encoded_data, bs.offset = start, 0
+    assert lib.decode_scan(C.byref(bs), img, C.byref(fh), sh, hts, qts, ri.value) == 0
+    end = bs.encoded_data - C.addressof(buf)
+    assert data[end:end + 2] == b"\xff\xd9" and bs.offset == 0
+    for c in range(fh.ncs):
+        p = g[f"plane{c}"]
+        assert np.array_equal(np.ctypeslib.as_array(img.contents.buf[c], shape=p.shape), p), f"Image.buf[{c}] differs"
+    H, W = g["rgb"].shape[:2]
+    fn = lib.y_rgb if fh.ncs == 1 else lib.ycbcr_rgb
+    fn.argtypes = [C.POINTER(_FrameHeader), C.POINTER(_Image), C.c_void_p, C.c_uint16, C.c_uint16, C.c_uint16]
+    pixels = np.zeros((H, 3 * W), np.uint8)
+    assert fn(C.byref(fh), img, pixels.ctypes.data, W, H, 3 * W) == 0
+    assert np.array_equal(pixels.reshape(H, W, 3), g["rgb"])
+    lib.free_img.argtypes = [C.POINTER(_Image)]
+    lib.free_img.restype = None
+    lib.free_img(img)
+    lib.free_huff_tables.argtypes = [C.c_void_p]
+    lib.free_huff_tables(hts)
+    lib.free_frame_header.argtypes = [C.POINTER(_FrameHeader)]
+    lib.free_frame_header(C.byref(fh))
+
+
 def _entropy_start(data):
     i = data.index(b"\xff\xda")
     return i + 2 + ((data[i + 2] << 8) | data[i + 3])
