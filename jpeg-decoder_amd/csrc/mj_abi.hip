@@ -78,10 +78,10 @@ constexpr size_t kStaticMetaBytes = 4u << 20;   /* page-locked mirror of the met
 /* offsets of every device buffer inside its region (all multiples of 256) */
 struct Offsets {
     /* meta */
-    size_t img, sets, tile_img, wg_img, pair_grp, idct_img, comb, meta_bytes;
+    size_t img, sets, tile_img, img_order, idct_img, comb, meta_bytes;
     /* state */
     size_t dyn, tile_cnt, tile_base, ivl_start, ivl_seq, seq_ivl, seq_sub, seq_entry, seq_seen, seq_flag, multi, multi_count,
-        stats, state_bytes;
+        grp_list, pair_list, stats, state_bytes;
     /* work */
     size_t raw, cmp, rec, work_bytes;
     /* out */
@@ -140,7 +140,8 @@ struct mj_batch {
     std::vector<MjImageDev> img;
     std::vector<mj_image_info> info;
     std::vector<MjHuffSet> sets;
-    std::vector<uint32_t> tile_img, wg_img, pair_grp;
+    std::vector<uint32_t> tile_img, img_order;
+    uint32_t n_pairs_cap = 0;           /* upper bound on the pairs of sequence groups (one image's, two at a time) */
     uint32_t n_busy_groups = 0;
     std::vector<MjIdctImg> idct_img;
     size_t n_files = 0;                /* img, info, idct_img also hold the extra units of files with several scans */
@@ -586,8 +587,8 @@ int layout(mj_batch *b, MjPrep &pp, uint32_t flags, bool may_span) {
     b->info.resize(n);
     b->sets.swap(pp.sets);          /* taken over, not copied: a set is 70 KB and a mixed batch has a hundred */
     b->tile_img.clear();
-    b->wg_img.clear();
-    b->pair_grp.clear();
+    b->img_order.clear();
+    b->n_pairs_cap = 0;
     b->n_busy_groups = 0;
     b->idct_img.assign((size_t) n, MjIdctImg{});
     b->n_files = pp.n_files;
@@ -718,22 +719,24 @@ int layout(mj_batch *b, MjPrep &pp, uint32_t flags, bool may_span) {
 
     /* Entropy workgroups, in the order the grids take them: the images whose lanes are longest
      * first (a workgroup lasts about as long as its lanes are; in a mixed batch the long ones
-     * started last would end the kernels alone), files of one lane length in the order given. */
+     * started last would end the kernels alone), files of one lane length in the order given.
+     * The host only knows an upper bound on an image's groups of sequences (seq_cap); the layout
+     * kernel, which knows the number, lists the groups that exist in this order of the images
+     * (mj_k_layout), and the entropy grids are sized by the bound. */
     {
-        std::vector<uint32_t> order((size_t) n);
-        for (int i = 0; i < n; i++) order[(size_t) i] = (uint32_t) i;
-        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+        b->img_order.resize((size_t) n);
+        for (int i = 0; i < n; i++) b->img_order[(size_t) i] = (uint32_t) i;
+        std::stable_sort(b->img_order.begin(), b->img_order.end(), [&](uint32_t x, uint32_t y) {
             return (uint64_t) b->img[x].sub_bits * b->img[x].lane_subs > (uint64_t) b->img[y].sub_bits * b->img[y].lane_subs;
         });
-        for (uint32_t i : order) {
-            MjImageDev &im = b->img[i];
-            im.wg_first = (uint32_t) n_wg;
-            const uint32_t wgs = (im.seq_cap + MJ_WG_SEQS - 1) / MJ_WG_SEQS;
+        uint64_t n_pairs = 0;
+        for (int i = 0; i < n; i++) {
+            const uint32_t wgs = (b->img[i].seq_cap + MJ_WG_SEQS - 1) / MJ_WG_SEQS;
             n_wg += wgs;
-            b->wg_img.insert(b->wg_img.end(), wgs, i);
-            for (uint32_t g = 0; g < wgs; g += 2) b->pair_grp.push_back(im.wg_first + g);
+            n_pairs += (wgs + 1) / 2;
         }
         if (n_wg >= (1ull << 31)) return set_err("batch too large");
+        b->n_pairs_cap = (uint32_t) n_pairs;
     }
 
     MjDeviceBatch &d = b->d;
@@ -769,8 +772,7 @@ int layout(mj_batch *b, MjPrep &pp, uint32_t flags, bool may_span) {
     o.img = m.take((uint64_t) n * sizeof(MjImageDev));
     o.sets = m.take(b->sets.size() * sizeof(MjHuffSet));
     o.tile_img = m.take(n_tiles * 4);
-    o.wg_img = m.take(n_wg * 4);
-    o.pair_grp = m.take(b->pair_grp.size() * 4);
+    o.img_order = m.take((uint64_t) n * 4);
     o.idct_img = m.take((uint64_t) n * sizeof(MjIdctImg));
     o.comb = m.take(b->comb.size() * sizeof(MjCombine));
     o.meta_bytes = m.off;
@@ -786,6 +788,8 @@ int layout(mj_batch *b, MjPrep &pp, uint32_t flags, bool may_span) {
     o.seq_flag = st.take(n_seq * 4);
     o.multi = st.take(n_multi * sizeof(uint2));
     o.multi_count = st.take(16);
+    o.grp_list = st.take(n_wg * sizeof(uint2));
+    o.pair_list = st.take((uint64_t) b->n_pairs_cap * sizeof(uint2));
     o.stats = st.take(MJ_ST_COUNT * sizeof(unsigned long long));
     o.state_bytes = st.off;
     o.raw = w.take(b->raw_bytes);
@@ -806,9 +810,8 @@ void bind(mj_batch *b, uint8_t *meta, uint8_t *state, uint8_t *work, uint8_t *co
     d.img = reinterpret_cast<const MjImageDev *>(meta + o.img);
     d.sets = reinterpret_cast<const MjHuffSet *>(meta + o.sets);
     d.tile_img = reinterpret_cast<const uint32_t *>(meta + o.tile_img);
-    d.wg_img = reinterpret_cast<const uint32_t *>(meta + o.wg_img);
-    d.pair_grp = reinterpret_cast<const uint32_t *>(meta + o.pair_grp);
-    d.n_sync_pairs = (uint32_t) b->pair_grp.size();
+    d.img_order = reinterpret_cast<const uint32_t *>(meta + o.img_order);
+    d.n_sync_pairs = b->n_pairs_cap;
     d.n_busy_groups = b->n_busy_groups;
     d.idct_img = reinterpret_cast<const MjIdctImg *>(meta + o.idct_img);
     d.comb = reinterpret_cast<const MjCombine *>(meta + o.comb);
@@ -824,6 +827,8 @@ void bind(mj_batch *b, uint8_t *meta, uint8_t *state, uint8_t *work, uint8_t *co
     d.seq_flag = reinterpret_cast<uint32_t *>(state + o.seq_flag);
     d.multi = reinterpret_cast<uint2 *>(state + o.multi);
     d.multi_count = reinterpret_cast<uint32_t *>(state + o.multi_count);
+    d.grp_list = reinterpret_cast<uint2 *>(state + o.grp_list);
+    d.pair_list = reinterpret_cast<uint2 *>(state + o.pair_list);
     d.stats = reinterpret_cast<unsigned long long *>(state + o.stats);
     d.raw = work + o.raw;
     d.cmp = work + o.cmp;
@@ -898,8 +903,7 @@ int upload(mj_batch *b, const std::vector<MjPrepared> &prep, uint8_t *meta, uint
     memcpy(mh + o.img, b->img.data(), n * sizeof(MjImageDev));
     memcpy(mh + o.sets, b->sets.data(), b->sets.size() * sizeof(MjHuffSet));
     memcpy(mh + o.tile_img, b->tile_img.data(), b->tile_img.size() * 4);
-    memcpy(mh + o.wg_img, b->wg_img.data(), b->wg_img.size() * 4);
-    memcpy(mh + o.pair_grp, b->pair_grp.data(), b->pair_grp.size() * 4);
+    memcpy(mh + o.img_order, b->img_order.data(), b->img_order.size() * 4);
     memcpy(mh + o.idct_img, b->idct_img.data(), n * sizeof(MjIdctImg));
     if (!b->comb.empty()) memcpy(mh + o.comb, b->comb.data(), b->comb.size() * sizeof(MjCombine));
     HIP_TRY(hipMemcpyAsync(meta, mh, o.meta_bytes, hipMemcpyHostToDevice, s));

@@ -132,7 +132,7 @@ typedef struct {
     uint32_t ivl_off;    /* first entry in the interval-start table (n_ivl + 1 entries) */
     uint32_t seq_off;    /* first sequence slot */
     uint32_t seq_cap;    /* sequence slots reserved (upper bound) */
-    uint32_t wg_first;   /* first entropy workgroup of this image */
+    uint32_t wg_first;   /* unused */
     uint32_t multi_cap;  /* upper bound on intervals longer than one sequence */
     uint32_t lane_subs;  /* consecutive subsequences one lane decodes (1..MJ_MAX_LANE_SUBS) */
     uint32_t rec_off;    /* first subsequence record of the image; sequence q starts at rec_off + q * 64 * lane_subs */

@@ -32,7 +32,7 @@ enum { MJ_ST_SUBS = 0, MJ_ST_ROUNDS, MJ_ST_MAXROUNDS, MJ_ST_SEQS, MJ_ST_MULTI, M
 struct MjDeviceBatch {
     uint32_t n_img;
     uint32_t n_tiles;        /* scan tiles over the whole batch */
-    uint32_t n_entropy_wg;   /* entropy workgroups (MJ_WG_SEQS sequences each) */
+    uint32_t n_entropy_wg;   /* upper bound on the groups of MJ_WG_SEQS sequences (the host knows how many an image has at most) */
     uint32_t n_multi_cap;    /* capacity of the multi-sequence interval list */
     uint32_t n_idct_tiles;   /* tiles of the dequant+IDCT+colour kernel (one wavefront works on a tile) */
     uint32_t want_planes;
@@ -58,10 +58,13 @@ struct MjDeviceBatch {
     MjState *seq_seen;       /* per sequence slot: entry state the fix-up last decoded from */
     uint32_t *seq_flag;      /* per sequence slot: scratch for the fix-up */
     uint2 *multi;            /* (image, interval) of intervals longer than one sequence */
-    uint32_t *multi_count;
-    const uint32_t *wg_img;  /* [n_entropy_wg] image of each entropy workgroup */
-    const uint32_t *pair_grp; /* [n_sync_pairs] first workgroup of every pair of workgroups of one image (an image's last pair may be a single one) */
-    uint32_t n_sync_pairs;
+    uint32_t *multi_count;   /* four counters, cleared before every decode: [0] entries in `multi`, [1] workgroups of the layout kernel
+                                that are through, [2] groups of sequences that exist (entries in grp_list), [3] entries in pair_list */
+    const uint32_t *img_order; /* [n_img] the images in the order their groups of sequences are listed (longest lanes first) */
+    uint2 *grp_list;         /* [n_entropy_wg at most] (image, group within the image) of every group of MJ_WG_SEQS sequences that exists,
+                                written by the layout kernel: block i of an entropy grid takes entry i */
+    uint2 *pair_list;        /* [n_sync_pairs at most] (image, first group) of every two groups of one image (its last may be a single one) */
+    uint32_t n_sync_pairs;   /* upper bound, like n_entropy_wg */
     uint32_t n_busy_groups;  /* lower bound on the workgroups that will hold work: per image the larger of its restart intervals and its bytes over a sequence's, in eights */
     const MjIdctImg *idct_img; /* [n_img] what the IDCT + colour kernel reads per image */
     const MjCombine *comb;   /* [n_comb] frames coded in one scan per component */

@@ -378,6 +378,21 @@ __device__ __forceinline__ void push_task(bool have, uint32_t task, uint32_t *qu
     if (have) queue[base + __popcll(mask & ((1ull << lane) - 1ull))] = task;
 }
 
+/* The sequence after sequence sw of the workgroup, if it continues the same interval (a decoder
+ * that is still out of step at the end of its sequence goes on there: the boundaries between
+ * the sequences of a workgroup are then settled by its rounds, and the cross-sequence kernels
+ * are left with the boundaries between workgroups); sw itself if there is none. */
+template <int SEQS>
+__device__ __forceinline__ uint32_t next_seq_here(const SeqGeo *s_geo, uint32_t sw, const SeqGeo &g, uint32_t SQ) {
+    /* only in intervals of four sequences or more (scans without restart markers): the one
+     * boundary of an interval that spills a little into a second sequence is cheaper left to
+     * the cross-sequence kernel, which has the whole chip for it, than made part of the chains
+     * the workgroup waits for (4K files with a restart interval per MCU row: 1.5 % of this kernel) */
+    if (sw + 1 >= (uint32_t) SEQS || g.nsub <= 3u * SQ) return sw;
+    const SeqGeo h = s_geo[sw + 1];
+    return (h.n != 0 && h.b0 == g.b0 && h.b1 == g.b1 && h.first == g.first + g.n) ? sw + 1 : sw;
+}
+
 constexpr int sync_groups(int spw) {       /* groups of MJ_WG_SEQS sequences one workgroup takes */
     return spw == 4 ? 2 : 1;
 }
@@ -390,12 +405,14 @@ __global__ __launch_bounds__(sync_threads(SYNC_SPW), SYNC_SPW >= 2 ? 5 : 4) void
     constexpr int SYNC_SEQS = sync_groups(SYNC_SPW) * MJ_WG_SEQS;
     constexpr int SYNC_TPB = sync_threads(SYNC_SPW);
     constexpr uint32_t SYNC_WAVES = SYNC_TPB / 64;
-    /* the first group of the block; with two groups to a block, the second is the next of the same image (if it has one) */
-    const uint32_t grp0 = (SYNC_SPW == 4) ? b.pair_grp[blockIdx.x] : blockIdx.x;
-    const uint32_t ii = b.wg_img[grp0];
+    /* the block's entry in the list of the groups that exist; with two groups to a block, the
+     * second is the next of the same image (if it has one) */
+    if (blockIdx.x >= b.multi_count[SYNC_SPW == 4 ? 3 : 2]) return;
+    const uint2 ge = (SYNC_SPW == 4) ? b.pair_list[blockIdx.x] : b.grp_list[blockIdx.x];
+    const uint32_t ii = ge.x;
     const MjImageDev &im = b.img[ii];
     const uint32_t n_seq = b.dyn[ii].n_seq;
-    const uint32_t seq0 = (grp0 - im.wg_first) * MJ_WG_SEQS;
+    const uint32_t seq0 = ge.y * MJ_WG_SEQS;
     if (seq0 >= n_seq) return;
 
     /* dynamic LDS: [tables][sequence geometry][3 queue counters][two queues][symbol-run tables] */
@@ -452,6 +469,14 @@ __global__ __launch_bounds__(sync_threads(SYNC_SPW), SYNC_SPW >= 2 ? 5 : 4) void
             }
             more = (u0 + GC < g.n);
             task = pack_task((L.c << 8) | L.k, L.p - (g.b0 + (j0 + GC) * S), sw, u0 + GC);
+            if (!more) {
+                /* the lane that ends its sequence goes on into the next one, where this workgroup has it */
+                const uint32_t nsw = next_seq_here<SYNC_SEQS>(s_geo, sw, g, SQ);
+                if (nsw != sw) {
+                    more = true;
+                    task = pack_task((L.c << 8) | L.k, L.p - (g.b0 + (g.first + g.n) * S), nsw, 0);
+                }
+            }
         }
         push_task(more, task, s_queue, &s_cnt[0]);
     }
@@ -497,8 +522,11 @@ __global__ __launch_bounds__(sync_threads(SYNC_SPW), SYNC_SPW >= 2 ? 5 : 4) void
                 const LaneRec r = solo_nowrite(cx, start + ((tw >> 10) & 31u), kc, sub_end(g.b0, g.b1, g.nsub, g.first + u, S), lane);
                 if (lane == 0) {
                     store_rec(dst, r);
-                    if (!(r.p == old.p && r.kc == old.kc) && (u + 1 < g.n)) {
-                        q_to[atomicAdd(&s_cnt[cn], 1u)] = pack_task(r.kc, r.p - (start + S), sw, u + 1);
+                    if (!(r.p == old.p && r.kc == old.kc)) {
+                        const uint32_t nsw = (u + 1 < g.n) ? sw : next_seq_here<SYNC_SEQS>(s_geo, sw, g, SQ);
+                        if (u + 1 < g.n || nsw != sw) {
+                            q_to[atomicAdd(&s_cnt[cn], 1u)] = pack_task(r.kc, r.p - (start + S), nsw, nsw == sw ? u + 1 : 0u);
+                        }
                     }
                 }
             }
@@ -515,8 +543,10 @@ __global__ __launch_bounds__(sync_threads(SYNC_SPW), SYNC_SPW >= 2 ? 5 : 4) void
                 const uint32_t start = g.b0 + (g.first + u) * S;
                 const LaneRec r = decode_nowrite(cx, start + ((tk >> 10) & 31u), kc, sub_end(g.b0, g.b1, g.nsub, g.first + u, S));
                 store_rec(dst, r);
-                more = !(r.p == old.p && r.kc == old.kc) && (u + 1 < g.n);
-                task = pack_task(r.kc, r.p - (start + S), sw, u + 1);
+                const bool differs = !(r.p == old.p && r.kc == old.kc);
+                const uint32_t nsw = (u + 1 < g.n) ? sw : next_seq_here<SYNC_SEQS>(s_geo, sw, g, SQ);
+                more = differs && (u + 1 < g.n || nsw != sw);
+                task = pack_task(r.kc, r.p - (start + S), nsw, nsw == sw ? u + 1 : 0u);
             }
             push_task(more, task, q_to, &s_cnt[cn]);
         }
@@ -561,11 +591,13 @@ __global__ __launch_bounds__(sync_threads(SYNC_SPW), SYNC_SPW >= 2 ? 5 : 4) void
  * in mj_k_entropy_fix.  That kernel then finds the entry states it would have used already
  * recorded in seq_seen, repeats only what changed since, and checks convergence as before. */
 __global__ __launch_bounds__(MJ_WG_SEQS * 64) void mj_k_entropy_fix_first(MjDeviceBatch b) {
-    const uint32_t ii = b.wg_img[blockIdx.x];
+    if (blockIdx.x >= b.multi_count[2]) return;
+    const uint2 ge = b.grp_list[blockIdx.x];
+    const uint32_t ii = ge.x;
     const MjImageDev &im = b.img[ii];
     const uint32_t n_seq = b.dyn[ii].n_seq;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
-    const uint32_t sq0 = (blockIdx.x - im.wg_first) * MJ_WG_SEQS;           /* first sequence (of the image) of the workgroup */
+    const uint32_t sq0 = ge.y * MJ_WG_SEQS;           /* first sequence (of the image) of the workgroup */
     /* lane t of every wavefront looks at sequence t, so all wavefronts decide alike whether to stay */
     const bool some = lane < MJ_WG_SEQS && sq0 + lane < n_seq && b.seq_sub[im.seq_off + sq0 + lane] != 0;
     if (!__any(some)) return;
@@ -760,10 +792,12 @@ __global__ __launch_bounds__(TPB) void mj_k_entropy_write(MjDeviceBatch b) {
 
     /* two workgroups of WAVES sequences per group of MJ_WG_SEQS */
     const uint32_t grp = blockIdx.x / (MJ_WG_SEQS / WAVES), part = blockIdx.x % (MJ_WG_SEQS / WAVES);
-    const uint32_t ii = b.wg_img[grp];
+    if (grp >= b.multi_count[2]) return;
+    const uint2 ge = b.grp_list[grp];
+    const uint32_t ii = ge.x;
     const MjImageDev &im = b.img[ii];
     const uint32_t n_seq = b.dyn[ii].n_seq;
-    const uint32_t seq0 = (grp - im.wg_first) * MJ_WG_SEQS + part * WAVES;
+    const uint32_t seq0 = ge.y * MJ_WG_SEQS + part * WAVES;
     if (seq0 >= n_seq) return;
     unsigned char *s_next = reinterpret_cast<unsigned char *>(s_list_lane + TPB);
     __shared__ uint8_t s_natpos[64];

@@ -298,6 +298,46 @@ __global__ __launch_bounds__(TPB) void mj_k_layout(MjDeviceBatch b) {
         dy.status = status;
         atomicAdd(&b.stats[MJ_ST_SEQS], (unsigned long long) carry);
     }
+
+    /* The workgroup that finishes last lists the groups of MJ_WG_SEQS sequences that exist, image
+     * after image in the host's order, and every two groups of one image: block i of an
+     * entropy grid takes entry i, so the blocks with work are the first of the grid and sit
+     * next to each other (the grids are sized by an upper bound on the sequences: the blocks
+     * past the end of the list leave at once). */
+    __shared__ uint32_t s_last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = (atomicAdd(&b.multi_count[1], 1u) == gridDim.x - 1u) ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    uint32_t carry_g = 0, carry_p = 0;
+    for (uint32_t i0 = 0; i0 < b.n_img; i0 += TPB) {
+        const uint32_t i = i0 + threadIdx.x;
+        uint32_t img = 0, g = 0;
+        if (i < b.n_img) {
+            img = b.img_order[i];
+            /* written by another workgroup of this kernel: read past this compute unit's cache */
+            const uint32_t nseq = __hip_atomic_load(&b.dyn[img].n_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            g = (nseq + MJ_WG_SEQS - 1) / MJ_WG_SEQS;
+        }
+        const uint32_t p = (g + 1) / 2;
+        uint32_t tg, tp;
+        const uint32_t eg = carry_g + block_excl_scan(g, s_w, &tg);
+        const uint32_t ep = carry_p + block_excl_scan(p, s_w, &tp);
+        for (uint32_t k = 0; k < g; k++) {
+            if (eg + k < b.n_entropy_wg) b.grp_list[eg + k] = make_uint2(img, k);
+        }
+        for (uint32_t k = 0; k < p; k++) {
+            if (ep + k < b.n_sync_pairs) b.pair_list[ep + k] = make_uint2(img, 2 * k);
+        }
+        carry_g += tg;
+        carry_p += tp;
+    }
+    if (threadIdx.x == 0) {
+        b.multi_count[2] = min(carry_g, b.n_entropy_wg);
+        b.multi_count[3] = min(carry_p, b.n_sync_pairs);
+    }
 }
 
 }  // namespace
