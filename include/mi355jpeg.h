@@ -89,12 +89,14 @@ int mj_device_pci_bus_id(int device, char *buf, size_t cap);
  * bufs[i] is borrowed for the duration of the call only.  Device memory is not cleared:
  * where a damaged stream leaves blocks undecoded, the outputs hold whatever was there.
  * Accepted: 8-bit SOF0 / SOF1 Huffman files, grey or three components, coded in one
- * interleaved scan (what the reference decodes, decode.c:535-663) or in one scan per
- * component (T.81 A.2.2; the reference has no defined output for those).  For a file of the
- * second kind mj_image_info reports blocks_per_mcu 1, n_blocks / entropy_bytes /
- * n_intervals summed over its scans and plane sizes padded to whole blocks;
- * mj_batch_copy_coefs returns the blocks scan after scan in the order of the file, each
- * scan in raster order of its component; the planes are always kept. */
+ * interleaved scan (what the reference decodes, decode.c:535-663) or in several scans that
+ * each hold one component, or one component alone and the other two together (T.81 A.2.2,
+ * A.2.3; the reference has no defined output for files of several scans).  For a file of the
+ * second kind mj_image_info reports n_blocks / entropy_bytes / n_intervals summed over its
+ * scans, blocks_per_mcu 1 when every scan holds one component and 0 otherwise, and the plane
+ * of a component padded to whole blocks when it has a scan of its own, to whole MCUs when it
+ * shares one; mj_batch_copy_coefs returns the blocks scan after scan in the order of the
+ * file, each scan in its own coding order; the planes are always kept. */
 int mj_batch_create(mj_ctx *ctx, const uint8_t *const *bufs, const size_t *lens, int n, uint32_t flags,
                     mj_batch **out);
 /* A batch of one image from already-parsed structs: what the reference hands to

@@ -123,13 +123,17 @@ struct mj_ctx {
     mj_batch *sbatch = nullptr;
 };
 
-/* A frame coded in one scan per component (T.81 A.2.2): every scan is decoded as a grey image of
- * its own (a "unit"), and a last kernel combines the three planes into the RGB of the file.
- * The unit of component 0 sits at the file's own index, the other two after all the files. */
+/* A three-component frame coded in several scans (T.81 A.2.2, A.2.3: one component each, or one
+ * alone and two interleaved): every scan is decoded as an image of its own (a "unit": grey for a
+ * scan of one component, two components for a scan of two), and a last kernel combines the
+ * planes into the RGB of the file.  The unit that holds component 0 sits at the file's own
+ * index, the others after all the files. */
 struct MjMultiScan {
     uint32_t file;
-    uint32_t unit[3];        /* by component */
-    uint32_t scan_unit[3];   /* in the order of the scans in the file */
+    uint32_t n_scans;        /* 2 or 3 */
+    uint32_t scan_unit[3];   /* unit of every scan, in the order of the scans in the file */
+    uint32_t unit[3];        /* by frame component: the unit that codes it ... */
+    uint32_t unit_comp[3];   /* ... and which of the unit's components it is */
     uint32_t hsf[3], vsf[3];
     uint32_t X, Y;
 };
@@ -288,9 +292,13 @@ int prepare_one(MjPrep &pp, MjPrepared &dst, const MjParsed &P, size_t len_after
     return 0;
 }
 
-/* A file whose first scan holds one of its three components: the three scans become three
- * grey units (decode.c:187-201 re-enters the scan loop for every SOS; the reference's own
- * bookkeeping does not survive that, see DESIGN, so the behaviour here is T.81's). */
+/* A file whose first scan holds one or two of its three components: every scan becomes a unit
+ * (decode.c:187-201 re-enters the scan loop for every SOS; the reference's own bookkeeping does
+ * not survive that -- its MCU counter runs on, decode.c:125, :473, :504 -- so the behaviour
+ * here is T.81's).  A scan of one component codes that component's own blocks in raster order
+ * (A.2.2): a grey image of the component's size.  A scan of two codes the frame's MCUs with
+ * those components' blocks only (A.2.3): an image of two components with the frame's sampling
+ * factors, as large as the larger of the two. */
 int prepare_scans(MjPrep &pp, size_t i, const uint8_t *buf, size_t len, MjParsed &P, const char **why, bool &freed) {
     const FrameHeader &fh = P.fh;
     if (fh.ncs != 3 || fh.precision != 8) {
@@ -311,40 +319,55 @@ int prepare_scans(MjPrep &pp, size_t i, const uint8_t *buf, size_t len, MjParsed
     mm.X = fh.X;
     mm.Y = fh.Y;
     MjPrepared part[3];
-    bool seen[3] = {false, false, false};
-    for (int scan = 0; scan < 3; scan++) {
-        if (P.sh.nics != 1) {
-            *why = "several scans: only scans of one component each are supported";
+    int scan_of[3] = {-1, -1, -1};      /* by component: the scan that codes it */
+    int n_seen = 0, n_scans = 0;
+    while (n_seen < 3) {
+        const int nics = P.sh.nics;
+        if (nics < 1 || nics > 2 || n_scans == 3) {
+            *why = "several scans: a scan must hold one or two components that no earlier scan has coded";
             return -1;
         }
-        int ci = -1;
-        for (int c = 0; c < 3; c++) {
-            if (fh.cs[c].id == P.sh.ics[0].sc) ci = c;
+        Component sub[2];
+        uint32_t uh = 0, uv = 0;
+        for (int s = 0; s < nics; s++) {
+            int ci = -1;
+            for (int c = 0; c < 3; c++) {
+                if (fh.cs[c].id == P.sh.ics[s].sc) ci = c;
+            }
+            if (ci < 0 || scan_of[ci] >= 0) {
+                *why = "several scans: a scan names an unknown component or one already coded";
+                return -1;
+            }
+            if (fh.cs[ci].hsf == 0 || fh.cs[ci].vsf == 0 || hmax % fh.cs[ci].hsf || vmax % fh.cs[ci].vsf) {
+                *why = "sampling factors that do not divide the maximum are not supported";
+                return -1;
+            }
+            scan_of[ci] = n_scans;
+            n_seen++;
+            mm.unit_comp[ci] = (uint32_t) s;
+            mm.hsf[ci] = fh.cs[ci].hsf;
+            mm.vsf[ci] = fh.cs[ci].vsf;
+            sub[s] = fh.cs[ci];
+            uh = sub[s].hsf > uh ? sub[s].hsf : uh;
+            uv = sub[s].vsf > uv ? sub[s].vsf : uv;
         }
-        if (ci < 0 || seen[ci]) {
-            *why = "several scans: a scan names an unknown component or one already coded";
-            return -1;
-        }
-        seen[ci] = true;
-        if (fh.cs[ci].hsf == 0 || fh.cs[ci].vsf == 0 || hmax % fh.cs[ci].hsf || vmax % fh.cs[ci].vsf) {
-            *why = "sampling factors that do not divide the maximum are not supported";
-            return -1;
-        }
-        mm.hsf[ci] = fh.cs[ci].hsf;
-        mm.vsf[ci] = fh.cs[ci].vsf;
-        /* the scan as a grey file of the component's own size */
         MjParsed Q = P;                    /* shares the tables' heap data with P, which outlives it */
-        Component one = fh.cs[ci];
-        one.hsf = one.vsf = 1;
-        Q.fh.cs = &one;
-        Q.fh.ncs = 1;
-        Q.fh.X = one.x;
-        Q.fh.Y = one.y;
+        Q.fh.cs = sub;
+        Q.fh.ncs = (uint8_t) nics;
+        if (nics == 1) {
+            /* the scan as a grey file of the component's own size */
+            sub[0].hsf = sub[0].vsf = 1;
+            Q.fh.X = sub[0].x;
+            Q.fh.Y = sub[0].y;
+        } else {
+            Q.fh.X = (uint16_t) (((uint32_t) fh.X * uh + hmax - 1) / hmax);
+            Q.fh.Y = (uint16_t) (((uint32_t) fh.Y * uv + vmax - 1) / vmax);
+        }
         const size_t ent_end = mj_scan_end(buf, len, P.ent_pos);
-        if (prepare_one(pp, part[ci], Q, ent_end, why) != 0) return -1;
-        part[ci].ent = buf + P.ent_pos;
-        mm.scan_unit[scan] = (uint32_t) ci;      /* component for now; unit index below */
-        if (scan < 2) {
+        if (prepare_one(pp, part[n_scans], Q, ent_end, why) != 0) return -1;
+        part[n_scans].ent = buf + P.ent_pos;
+        n_scans++;
+        if (n_seen < 3) {
             const int r = mj_parse_next_scan(buf, len, ent_end, &P, why);
             if (r != 0) {
                 if (r == 1) *why = "several scans: the file ends before every component was coded";
@@ -353,13 +376,20 @@ int prepare_scans(MjPrep &pp, size_t i, const uint8_t *buf, size_t len, MjParsed
             }
         }
     }
-    pp.img[i] = part[0];
-    mm.unit[0] = (uint32_t) i;
-    for (int c = 1; c < 3; c++) {
-        mm.unit[c] = (uint32_t) pp.img.size();
-        pp.img.push_back(part[c]);
+    /* the unit of component 0 takes the file's place, the others go to the end of the list */
+    uint32_t unit_of_scan[3] = {0, 0, 0};
+    for (int sc = 0; sc < n_scans; sc++) {
+        if (sc == scan_of[0]) {
+            pp.img[i] = part[sc];
+            unit_of_scan[sc] = (uint32_t) i;
+        } else {
+            unit_of_scan[sc] = (uint32_t) pp.img.size();
+            pp.img.push_back(part[sc]);
+        }
+        mm.scan_unit[sc] = unit_of_scan[sc];
     }
-    for (int scan = 0; scan < 3; scan++) mm.scan_unit[scan] = mm.unit[mm.scan_unit[scan]];
+    mm.n_scans = (uint32_t) n_scans;
+    for (int c = 0; c < 3; c++) mm.unit[c] = unit_of_scan[scan_of[c]];
     pp.multi.push_back(mm);
     return 0;
 }
@@ -391,7 +421,7 @@ int prepare_file(MjPrep &pp, MjPrepared &dst, size_t i, const uint8_t *buf, size
         snprintf(msg, msg_cap, "%s", why);       /* the parser freed what it had */
         return -1;
     }
-    if (P.sh.nics == 1 && P.fh.ncs == 3) {
+    if (P.sh.nics < P.fh.ncs && P.fh.ncs == 3) {
         if (defer) {
             *defer = true;
             mj_parsed_free(&P);
@@ -405,6 +435,11 @@ int prepare_file(MjPrep &pp, MjPrepared &dst, size_t i, const uint8_t *buf, size
         }
         mj_parsed_free(&P);
         return 0;
+    }
+    if (P.fh.ncs != 1 && P.fh.ncs != 3) {
+        mj_parsed_free(&P);
+        snprintf(msg, msg_cap, "only grey and three-component images are supported");
+        return -1;
     }
     if (prepare_one(pp, dst, P, len, &why) != 0) {
         mj_parsed_free(&P);
@@ -689,17 +724,23 @@ int layout(mj_batch *b, MjPrep &pp, uint32_t flags, bool may_span) {
         inf.n_intervals = 0;
         for (int c = 0; c < 3; c++) {
             const MjImageDev &u = b->img[mm.unit[c]];
-            cb.plane_off[c] = u.comp[0].plane_off;
-            cb.pw[c] = u.comp[0].pw;
+            const MjCompDev &uc = u.comp[mm.unit_comp[c]];
+            cb.plane_off[c] = uc.plane_off;
+            cb.pw[c] = uc.pw;
             cb.hsf[c] = mm.hsf[c];
             cb.vsf[c] = mm.vsf[c];
             inf.hsf[c] = (int32_t) mm.hsf[c];
             inf.vsf[c] = (int32_t) mm.vsf[c];
-            inf.plane_w[c] = (int32_t) u.comp[0].pw;
-            inf.plane_h[c] = (int32_t) u.comp[0].ph;
+            inf.plane_w[c] = (int32_t) uc.pw;
+            inf.plane_h[c] = (int32_t) uc.ph;
+        }
+        bool all_single = true;
+        for (uint32_t sc = 0; sc < mm.n_scans; sc++) {
+            const MjImageDev &u = b->img[mm.scan_unit[sc]];
             inf.n_blocks += (int64_t) u.n_mcu * u.bpm;
             inf.entropy_bytes += (int64_t) u.raw_len;
             inf.n_intervals += (int32_t) u.n_ivl;
+            all_single = all_single && u.ncs == 1;
         }
         const MjImageDev &y = b->img[mm.unit[0]];
         cb.ncs = 3;
@@ -711,7 +752,7 @@ int layout(mj_batch *b, MjPrep &pp, uint32_t flags, bool may_span) {
         cb.rgb_off = y.rgb_off;
         inf.mcus_x = (int32_t) ((mm.X + 8 * cb.hmax - 1) / (8 * cb.hmax));
         inf.mcus_y = (int32_t) ((mm.Y + 8 * cb.vmax - 1) / (8 * cb.vmax));
-        inf.blocks_per_mcu = 1;            /* every scan codes one block at a time */
+        inf.blocks_per_mcu = all_single ? 1 : 0;      /* one block at a time in every scan, or it differs from scan to scan */
         comb_max_x = mm.X > comb_max_x ? mm.X : comb_max_x;
         comb_max_y = mm.Y > comb_max_y ? mm.Y : comb_max_y;
         b->comb.push_back(cb);
@@ -1209,6 +1250,7 @@ int mj_batch_create_scan(mj_ctx *ctx, const uint8_t *entropy, size_t entropy_len
                          const ScanHeader *sh, const HuffTables *hts, const QuantTables *qts, RestartInterval ri,
                          uint32_t flags, mj_batch **out) {
     if (!ctx || !entropy || !fh || !sh || !hts || !qts || !out) return set_err("mj_batch_create_scan: bad arguments");
+    if (fh->ncs != 1 && fh->ncs != 3) return set_err("mj_batch_create_scan: only grey and three-component images are supported");
     HIP_TRY(hipSetDevice(ctx->device));
     MjParsed P;
     memset(&P, 0, sizeof P);
@@ -1453,8 +1495,8 @@ int mj_batch_status(mj_batch *b, int i, uint32_t *status) {
     HIP_TRY(hipMemcpy(&dy, b->d.dyn + i, sizeof dy, hipMemcpyDeviceToHost));
     *status = dy.status;
     if (const MjMultiScan *mm = multi_of(b, i)) {        /* any of its scans */
-        for (int c = 1; c < 3; c++) {
-            HIP_TRY(hipMemcpy(&dy, b->d.dyn + mm->unit[c], sizeof dy, hipMemcpyDeviceToHost));
+        for (uint32_t sc = 0; sc < mm->n_scans; sc++) {
+            HIP_TRY(hipMemcpy(&dy, b->d.dyn + mm->scan_unit[sc], sizeof dy, hipMemcpyDeviceToHost));
             *status |= dy.status;
         }
     }
@@ -1502,7 +1544,7 @@ int mj_batch_copy_coefs(mj_batch *b, int i, int16_t *dst) {
     size_t n_blocks = 0;
     if (const MjMultiScan *mm = multi_of(b, i)) {
         /* scan after scan, in the order of the file */
-        for (int sc = 0; sc < 3; sc++) {
+        for (uint32_t sc = 0; sc < mm->n_scans; sc++) {
             const MjImageDev &u = b->img[mm->scan_unit[sc]];
             const size_t nb = (size_t) u.n_mcu * u.bpm;
             HIP_TRY(hipMemcpy(dst + n_blocks * 64, b->d.coefs + u.coef_off * 64, nb * 128, hipMemcpyDeviceToHost));
@@ -1530,7 +1572,7 @@ int mj_batch_copy_plane(mj_batch *b, int i, int comp, uint8_t *dst) {
     if (const MjMultiScan *mm = multi_of(b, i)) {        /* the plane of the component's own scan */
         if (comp < 0 || comp >= 3) return set_err("mj_batch_copy_plane: no such component");
         i = (int) mm->unit[comp];
-        comp = 0;
+        comp = (int) mm->unit_comp[comp];
     }
     const MjImageDev &im = b->img[i];
     if (comp < 0 || comp >= (int) im.ncs) return set_err("mj_batch_copy_plane: no such component");

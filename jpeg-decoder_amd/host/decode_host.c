@@ -236,7 +236,7 @@ out:
     return rc;
 }
 
-/* A frame coded in one scan per component: the reference would re-enter decode_scan for every
+/* A frame coded in several scans (one per component, or one component alone and two together): the reference would re-enter decode_scan for every
  * SOS (decode.c:187-201, :333) and write past its planes from the second on (its MCU counter
  * runs on, decode.c:125, :473, :504).  Here the whole file goes to the batch entry point once,
  * which knows such files; the planes of the three scans land in the Image (rows at the Image's
@@ -360,8 +360,8 @@ int decode_jpeg_buffer(uint8_t *buf, size_t len, FrameHeader *fh, Image **img) {
                 if (decode_scan_header(&bs, &sh) != 0) { rc = -1; break; }
                 print_scan_header(&sh);
                 if (!have_qts || !have_hts || !have_fh || !im) { rc = -1; break; }
-                if (sh.nics == 1 && fh->ncs == 3) {
-                    /* one scan per component: all of them at once, and the walk is over */
+                if (sh.nics < fh->ncs && fh->ncs == 3) {
+                    /* the frame takes several scans: all of them at once, and the walk is over */
                     if (decode_all_scans(buf, len, im) != 0) rc = -1;
                     bs.encoded_data = (uint8_t *) end;
                     advance = 0;

@@ -495,7 +495,7 @@ int mj_flatten_image(const MjParsed *p, size_t file_len, MjImageDev *img, MjHuff
     if (fh->precision != 8) {
         return fail(why, "only 8-bit samples are supported");
     }
-    if (fh->ncs != 1 && fh->ncs != 3) {
+    if (fh->ncs < 1 || fh->ncs > 3) {     /* two: a scan of two of a frame's three components, taken as an image of its own */
         return fail(why, "only grey and three-component images are supported");
     }
     if (sh->nics != fh->ncs) {

@@ -42,13 +42,17 @@ def synth_image(width, height, seed, sigma=12.0, grey=False):
     return np.ascontiguousarray(out[..., 0]) if grey else out
 
 
-def encode_jpeg(pixels, sampling="4:2:0", quality=85, restart_interval=0, optimise=False, ycc=False, scans_per_component=False):
+def encode_jpeg(pixels, sampling="4:2:0", quality=85, restart_interval=0, optimise=False, ycc=False, scans_per_component=False,
+                scans=None):
     """Baseline SOF0 JPEG bytes for an (H, W, 3) RGB or (H, W) grey uint8 array.
     restart_interval is in MCUs; 0 means no DRI segment.  optimise: Huffman tables fitted
     to the image (T.81 Annex K.2) instead of the Annex K typical tables.  ycc: the three
     channels are Y, Cb, Cr already and go into the file as they are.  scans_per_component: one
     non-interleaved scan per component instead of one interleaved scan (restart_interval then
-    counts blocks of the component)."""
+    counts blocks of the component).  scans: "y|cbcr" (luma alone, then the two chroma components
+    interleaved) or "ycb|cr" (luma and Cb interleaved, then Cr alone); restart_interval counts
+    each scan's own MCUs."""
+    scan_bits = {None: 0, "y|cbcr": 8, "ycb|cr": 16}[scans]
     lib = _load()
     a = np.ascontiguousarray(pixels, np.uint8)
     if a.ndim == 2:
@@ -60,7 +64,7 @@ def encode_jpeg(pixels, sampling="4:2:0", quality=85, restart_interval=0, optimi
     cap = w * h * ncomp + (1 << 16)
     for _ in range(2):
         out = np.empty(cap, np.uint8)
-        n = lib.mjs_encode2(a.ctypes.data, w, h, ncomp, hs, vs, int(quality), int(restart_interval), (1 if optimise else 0) | (2 if ycc else 0) | (4 if scans_per_component else 0),
+        n = lib.mjs_encode2(a.ctypes.data, w, h, ncomp, hs, vs, int(quality), int(restart_interval), (1 if optimise else 0) | (2 if ycc else 0) | (4 if scans_per_component else 0) | scan_bits,
                             out.ctypes.data, cap)
         if n < 0:
             raise ValueError("mjs_encode: bad arguments")

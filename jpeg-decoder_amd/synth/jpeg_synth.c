@@ -315,6 +315,72 @@ static void put_dht(BW *w, int tc_th, const uint8_t *bits, const uint8_t *vals) 
  * Returns the number of bytes the stream needs; it is complete only if that is
  * <= cap.  Negative on bad arguments.
  */
+/* One scan over the frame components grp[0 .. n) of a three-component frame whose quantised
+ * blocks Q lie in interleaved MCU order (bpm blocks per MCU: hs * vs of component 0, then one
+ * each of components 1 and 2).  n = 1: the component's own blocks in raster order, those that
+ * only pad the MCU grid left out (T.81 A.2.2); n > 1: the frame's MCU grid with the blocks of
+ * the scan's components only (A.2.3).  ri counts the scan's own MCUs (blocks when n = 1).
+ * With w = NULL nothing is written and the symbols are counted in freq (DC luma, AC luma, DC
+ * chroma, AC chroma) instead. */
+static void code_scan(BW *w, const int *grp, int n, const int16_t *Q, int W, int H, int hs, int vs, int mx, int my, int ri,
+                      const EncTab *dcl, const EncTab *acl, const EncTab *dcc, const EncTab *acc, long (*freq)[256]) {
+    const int bpm = hs * vs + 2;
+    int pred[3] = {0, 0, 0}, rst = 0;
+    int64_t done = 0;
+    if (n == 1) {
+        const int c = grp[0];
+        const int hc = c ? 1 : hs, vc = c ? 1 : vs, base = c ? hs * vs + (c - 1) : 0;
+        const int xc = (W * hc + hs - 1) / hs, yc = (H * vc + vs - 1) / vs;     /* samples of the component */
+        const int bw_c = (xc + 7) / 8, bh_c = (yc + 7) / 8;
+        for (int by = 0; by < bh_c; by++) {
+            for (int bx = 0; bx < bw_c; bx++, done++) {
+                if (ri && done && (done % ri) == 0) {
+                    if (w) {
+                        bw_flush(w);
+                        bw_byte(w, 0xFF);
+                        bw_byte(w, 0xD0 + (rst++ & 7));
+                    }
+                    pred[c] = 0;
+                }
+                const int64_t mcu = (int64_t) (by / vc) * mx + bx / hc;
+                const int16_t *q = Q + (mcu * bpm + base + (by % vc) * hc + bx % hc) * 64;
+                enc_block(w, q, &pred[c], c ? dcc : dcl, c ? acc : acl, freq ? freq[c ? 2 : 0] : NULL, freq ? freq[c ? 3 : 1] : NULL);
+            }
+        }
+    } else {
+        for (int64_t m = 0; m < (int64_t) mx * my; m++, done++) {
+            if (ri && done && (done % ri) == 0) {
+                if (w) {
+                    bw_flush(w);
+                    bw_byte(w, 0xFF);
+                    bw_byte(w, 0xD0 + (rst++ & 7));
+                }
+                pred[0] = pred[1] = pred[2] = 0;
+            }
+            for (int g = 0; g < n; g++) {
+                const int c = grp[g];
+                const int nb = c ? 1 : hs * vs, base = c ? hs * vs + (c - 1) : 0;
+                for (int i = 0; i < nb; i++) {
+                    enc_block(w, Q + (m * bpm + base + i) * 64, &pred[c], c ? dcc : dcl, c ? acc : acl, freq ? freq[c ? 2 : 0] : NULL,
+                              freq ? freq[c ? 3 : 1] : NULL);
+                }
+            }
+        }
+    }
+    if (w) bw_flush(w);
+}
+
+/* how the three components are dealt out over the scans: flags bit 2 one scan each, bit 3
+ * (Y)(Cb Cr), bit 4 (Y Cb)(Cr); groups end with -1 */
+static int scan_groups(int flags, int grp[3][4]) {
+    static const int per_comp[3][4] = {{0, -1}, {1, -1}, {2, -1}};
+    static const int y_cbcr[3][4] = {{0, -1}, {1, 2, -1}, {-1}};
+    static const int ycb_cr[3][4] = {{0, 1, -1}, {2, -1}, {-1}};
+    const int (*src)[4] = (flags & 8) ? y_cbcr : (flags & 16) ? ycb_cr : per_comp;
+    memcpy(grp, src, sizeof per_comp);
+    return (flags & (8 | 16)) ? 2 : 3;
+}
+
 int64_t mjs_encode2(const uint8_t *pix, int W, int H, int ncomp, int hs, int vs, int quality, int ri, int flags,
                     uint8_t *out, size_t cap);
 
@@ -466,6 +532,17 @@ int64_t mjs_encode2(const uint8_t *pix, int W, int H, int ncomp, int hs, int vs,
                 }
             }
         }
+        if ((flags & (8 | 16)) && ncomp == 3) {
+            /* scans that interleave some of the components: the symbols as those scans code them */
+            int grp[3][4];
+            const int ns = scan_groups(flags, grp);
+            memset(freq, 0, sizeof freq);
+            for (int sc = 0; sc < ns; sc++) {
+                int n = 0;
+                while (grp[sc][n] >= 0) n++;
+                code_scan(NULL, grp[sc], n, Q, W, H, hs, vs, mx, my, ri, NULL, NULL, NULL, NULL, freq);
+            }
+        }
         for (int t = 0; t < (ncomp == 3 ? 4 : 2); t++) fit_table(freq[t], bits[t], vals[t]);
     }
     EncTab dcl, dcc, acl, acc;
@@ -498,6 +575,27 @@ int64_t mjs_encode2(const uint8_t *pix, int W, int H, int ncomp, int hs, int vs,
     }
     if (ri) {
         bw_byte(&w, 0xFF); bw_byte(&w, 0xDD); bw_u16(&w, 4); bw_u16(&w, ri);
+    }
+    if ((flags & (8 | 16)) && ncomp == 3) {
+        /* two scans: one component alone, the other two interleaved (or the other way round) */
+        int grp[3][4];
+        const int ns = scan_groups(flags, grp);
+        for (int sc = 0; sc < ns; sc++) {
+            int n = 0;
+            while (grp[sc][n] >= 0) n++;
+            bw_byte(&w, 0xFF); bw_byte(&w, 0xDA); bw_u16(&w, 6 + 2 * n); bw_byte(&w, n);
+            for (int g = 0; g < n; g++) {
+                bw_byte(&w, grp[sc][g] + 1); bw_byte(&w, grp[sc][g] ? 0x11 : 0x00);
+            }
+            bw_byte(&w, 0); bw_byte(&w, 63); bw_byte(&w, 0);
+            code_scan(&w, grp[sc], n, Q, W, H, hs, vs, mx, my, ri, &dcl, &acl, &dcc, &acc, NULL);
+        }
+        bw_byte(&w, 0xFF); bw_byte(&w, 0xD9);
+        free(Q);
+        free(Yp);
+        free(Cb);
+        free(Cr);
+        return (int64_t) w.pos;
     }
     if ((flags & 4) && ncomp == 3) {
         /* three scans of one component each */

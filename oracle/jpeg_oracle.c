@@ -16,8 +16,8 @@
  *   - grey output reads the padded plane with its real stride
  *     (colour_conversion.c:20 strides by the image width).
  *
- * Files whose frame is coded in several scans of one component each (T.81 A.2.2, B.2.3) are
- * decoded by orc_run_scans below.  PARITY UNPINNED for that path: the reference re-enters its
+ * Files whose three-component frame is coded in several scans (one component each, or one alone
+ * and two together: T.81 A.2.2, A.2.3, B.2.3) are decoded by orc_run_scans below.  PARITY UNPINNED for that path: the reference re-enters its
  * scan loop without resetting its MCU counter (decode.c:125, :473, :504) and writes past its
  * planes, so it has no output to be equal to; the tests pin this path instead against the
  * interleaved coding of the same coefficients, which the reference does decode.
@@ -570,7 +570,7 @@ static int orc_colour(const OJpeg *j, uint8_t **plane, uint8_t *rgb, int pitch) 
 }
 
 /* ------------------------------------------------------------------------ */
-/* several scans of one component each                                      */
+/* frames coded in several scans                                            */
 /* ------------------------------------------------------------------------ */
 /* where the entropy-coded segment that starts at p ends: the next marker that is neither a
  * stuffed FF00, a fill byte nor RSTn (T.81 B.1.1.5) */
@@ -584,10 +584,12 @@ static const uint8_t *oscan_end(const uint8_t *p, const uint8_t *end) {
     return end;
 }
 
-/* T.81 A.2.2: a scan of one component codes its ceil(x/8) x ceil(y/8) blocks in raster order;
- * the restart interval counts blocks; tables are those in force at its SOS.  Coefficients come
- * out scan after scan in coding order, planes are padded to whole blocks, and the colour stage
- * is the reference's (colour_conversion.c:30-83) on those planes. */
+/* T.81 A.2.2: a scan of one component codes its ceil(x/8) x ceil(y/8) blocks in raster order and
+ * the restart interval counts blocks; A.2.3: a scan of two of the three components codes the
+ * frame's MCUs with those components' blocks only.  Tables are those in force at the scan's SOS.
+ * Coefficients come out scan after scan in coding order, the plane of a component coded alone is
+ * padded to whole blocks, that of one coded with another to whole MCUs, and the colour stage is
+ * the reference's (colour_conversion.c:30-83) on those planes. */
 static int orc_run_scans(const uint8_t *buf, size_t len, int want_tap, int want_rgb, OrcOut *out) {
     OJpeg *j = (OJpeg *) calloc(1, sizeof(OJpeg));
     int16_t *coefs = NULL;
@@ -635,14 +637,42 @@ static int orc_run_scans(const uint8_t *buf, size_t len, int want_tap, int want_
         } else if (m >= 0xC2 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
             goto done;
         } else if (m == 0xDA) {
-            if (!have_sof || parse_sos(j, body, blen) || j->nscan != 1) goto done;
-            const int ci = j->scan_comp[0];
-            const OComp *c = &j->c[ci];
-            if (seen[ci]) goto done;
-            seen[ci] = 1;
+            if (!have_sof || parse_sos(j, body, blen) || j->nscan < 1 || j->nscan > 2) goto done;
+            for (int i = 0; i < j->nscan; i++) {
+                if (seen[j->scan_comp[i]]) goto done;
+                seen[j->scan_comp[i]] = 1;
+            }
             const uint8_t *ent = buf + pos + seglen, *end = oscan_end(ent, buf + len);
-            const int bw = c->pw / 8, bh = c->ph / 8;
-            const int64_t nb = (int64_t) bw * bh;
+            int mcus_x, mcus_y, bpm = 0;
+            if (j->nscan == 1) {
+                /* A.2.2: the component's own blocks, one per "MCU" */
+                const OComp *c = &j->c[j->scan_comp[0]];
+                mcus_x = c->pw / 8;
+                mcus_y = c->ph / 8;
+                bpm = 1;
+            } else {
+                /* A.2.3: the frame's MCU grid with the blocks of the scan's components only; their
+                 * planes are padded to whole MCUs */
+                int hmax = 1, vmax = 1;
+                for (int i = 0; i < 3; i++) {
+                    hmax = j->c[i].hsf > hmax ? j->c[i].hsf : hmax;
+                    vmax = j->c[i].vsf > vmax ? j->c[i].vsf : vmax;
+                }
+                mcus_x = (j->X + 8 * hmax - 1) / (8 * hmax);
+                mcus_y = (j->Y + 8 * vmax - 1) / (8 * vmax);
+                for (int i = 0; i < j->nscan; i++) {
+                    const int ci = j->scan_comp[i];
+                    OComp *c = &j->c[ci];
+                    c->pw = mcus_x * 8 * c->hsf;
+                    c->ph = mcus_y * 8 * c->vsf;
+                    out->plane_w[ci] = c->pw;
+                    out->plane_h[ci] = c->ph;
+                    free(out->plane[ci]);
+                    out->plane[ci] = (uint8_t *) calloc((size_t) c->pw * c->ph + 16, 1);
+                    bpm += c->hsf * c->vsf;
+                }
+            }
+            const int64_t nmcu = (int64_t) mcus_x * mcus_y, nb = nmcu * bpm;
             if (nb_total + nb > nb_cap) {
                 nb_cap = (nb_total + nb) * 2;
                 coefs = (int16_t *) realloc(coefs, (size_t) nb_cap * 64 * sizeof(int16_t) + 16);
@@ -650,19 +680,29 @@ static int orc_run_scans(const uint8_t *buf, size_t len, int want_tap, int want_
             int16_t *cs = coefs + nb_total * 64;
             memset(cs, 0, (size_t) nb * 64 * sizeof(int16_t));
             OBits b = {ent, buf + len, 0};
-            const OHuff *dc = &j->ht[0][c->dc & 3], *ac = &j->ht[1][c->ac & 3];
-            int16_t pred = 0, px[64];
-            for (int64_t k = 0; k < nb; k++) {
-                if (j->ri && k && (k % j->ri) == 0) {
+            int16_t pred[4] = {0, 0, 0, 0}, px[64];
+            int64_t k = 0;
+            for (int64_t m = 0; m < nmcu; m++) {
+                if (j->ri && m && (m % j->ri) == 0) {
                     orestart(&b);
-                    pred = 0;
+                    memset(pred, 0, sizeof pred);
                 }
-                oblock(&b, dc, ac, &pred, cs + k * 64);
-                orc_dequant_idct(cs + k * 64, j->qt[c->qtid & 3], px);
-                const int x0 = 8 * (int) (k % bw), y0 = 8 * (int) (k / bw);
-                for (int r = 0; r < 8; r++) {
-                    for (int q = 0; q < 8; q++) {
-                        out->plane[ci][(size_t) (y0 + r) * c->pw + x0 + q] = (uint8_t) px[8 * r + q];
+                for (int i = 0; i < j->nscan; i++) {
+                    const int ci = j->scan_comp[i];
+                    const OComp *c = &j->c[ci];
+                    const OHuff *dc = &j->ht[0][c->dc & 3], *ac = &j->ht[1][c->ac & 3];
+                    const int nh = j->nscan == 1 ? 1 : c->hsf, nv = j->nscan == 1 ? 1 : c->vsf;
+                    for (int v = 0; v < nv; v++) {
+                        for (int h = 0; h < nh; h++, k++) {
+                            oblock(&b, dc, ac, &pred[i], cs + k * 64);
+                            orc_dequant_idct(cs + k * 64, j->qt[c->qtid & 3], px);
+                            const int x0 = 8 * ((int) (m % mcus_x) * nh + h), y0 = 8 * ((int) (m / mcus_x) * nv + v);
+                            for (int r = 0; r < 8; r++) {
+                                for (int q = 0; q < 8; q++) {
+                                    out->plane[ci][(size_t) (y0 + r) * c->pw + x0 + q] = (uint8_t) px[8 * r + q];
+                                }
+                            }
+                        }
                     }
                 }
             }
@@ -702,9 +742,9 @@ static int orc_run(const uint8_t *buf, size_t len, int want_tap, int want_rgb, O
         free(j);
         return -1;
     }
-    if (j->nscan == 1 && j->ncs == 3 && j->precision == 8 && !rgb_reuse) {
+    if (j->nscan < j->ncs && j->ncs == 3 && j->precision == 8 && !rgb_reuse) {
         free(j);
-        return orc_run_scans(buf, len, want_tap, want_rgb, out);   /* one scan per component */
+        return orc_run_scans(buf, len, want_tap, want_rgb, out);   /* the frame takes several scans */
     }
     if (j->nscan != j->ncs || j->precision != 8) {
         free(j);

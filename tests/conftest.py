@@ -97,3 +97,27 @@ def scans_per_component_pair(case):
     img = J.synth.synth_image(w, h, seed=w * 3 + h)
     return (J.synth.encode_jpeg(img, sampling, q, ri, optimise=fitted, scans_per_component=True),
             J.synth.encode_jpeg(img, sampling, q, ri, optimise=fitted))
+
+
+SCAN_GROUP_CASES = [
+    # (w, h, sampling, quality, restart interval, fitted tables, how the components are dealt out over two scans)
+    (96, 64, "4:2:0", 85, 0, False, "y|cbcr"),
+    (100, 75, "4:2:0", 85, 0, True, "y|cbcr"),        # ragged edges: the luma scan codes fewer blocks than the MCU grid has
+    (100, 75, "4:2:0", 85, 5, True, "ycb|cr"),
+    (203, 77, "4:2:2", 90, 7, False, "y|cbcr"),       # restart intervals counted in each scan's own MCUs
+    (131, 77, "4:4:4", 75, 5, False, "ycb|cr"),
+    (64, 48, "4:1:1", 60, 0, True, "ycb|cr"),
+    (50, 70, "4:4:0", 95, 3, False, "y|cbcr"),
+    (331, 316, "4:2:0", 86, 11, True, "y|cbcr"),
+    (615, 25, "4:4:0", 80, 0, True, "ycb|cr"),
+]
+
+
+def scan_group_pair(case):
+    """(file whose frame takes two scans -- one component alone, two interleaved --, the same
+    coefficients in one interleaved scan)."""
+    import jpeg_decoder_amd as J
+    w, h, sampling, q, ri, fitted, scans = case
+    img = J.synth.synth_image(w, h, seed=w * 5 + h)
+    return (J.synth.encode_jpeg(img, sampling, q, ri, optimise=fitted, scans=scans),
+            J.synth.encode_jpeg(img, sampling, q, ri and 3, optimise=fitted))

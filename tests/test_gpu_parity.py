@@ -227,6 +227,70 @@ def test_frames_coded_in_one_scan_per_component(ctx, oracle, flags):
     b.close()
 
 
+@pytest.mark.parametrize("flags", [0, binding.MJ_OUT_RGBA, binding.MJ_ENTROPY_SERIAL])
+def test_frames_coded_in_scans_of_some_of_the_components(ctx, oracle, flags):
+    """Files of two scans -- luma alone then both chroma components interleaved, or luma and Cb
+    interleaved then Cr alone (T.81 A.2.2, A.2.3) -- mixed with their interleaved twins and with
+    files of one scan per component in one batch: coefficients (scan after scan), the planes
+    and RGB against the restatement, and RGB against the twin (which the reference decodes).
+    Parity with the reference itself is unpinned: it has no output for files of several scans."""
+    from conftest import SCAN_GROUP_CASES, scan_group_pair
+    files, want = [], []
+    for case in SCAN_GROUP_CASES:
+        multi, inter = scan_group_pair(case)
+        files += [multi, inter]
+        want += [oracle.decode(multi), oracle.decode(inter)]
+    n_pairs = len(files)
+    for extra in (J.synth.encode_jpeg(J.synth.synth_image(1280, 720, seed=4), "4:2:0", 88, 0, scans="y|cbcr"),
+                  J.synth.encode_jpeg(J.synth.synth_image(640, 480, seed=5), "4:2:2", 80, 40, scans="ycb|cr", optimise=True),
+                  scans_per_component_pair(SCANS_PER_COMPONENT_CASES[2])[0]):
+        files.append(extra)
+        want.append(oracle.decode(extra))
+    b = ctx.batch(files, flags)
+    b.decode()
+    for i, o in enumerate(want):
+        assert b.status(i) == 0, i
+        assert np.array_equal(b.coefs(i), o.coefs), f"file {i}: coefficients"
+        out = b.rgb(i)
+        assert np.array_equal(out[..., :3], o.rgb), f"file {i}: RGB"
+        if i % 2 == 0 or i >= n_pairs:
+            for c, p in enumerate(o.planes):
+                assert np.array_equal(b.plane(i, c), p), f"file {i}: plane {c}"
+        if i % 2 == 0 and i < n_pairs:
+            assert np.array_equal(o.rgb, want[i + 1].rgb)
+    b.close()
+
+
+def test_dropin_api_on_a_file_of_two_scans(ctx, oracle):
+    """decode_jpeg_buffer + ycbcr_rgb on a frame whose luma has a scan of its own and whose chroma
+    components share one: planes at the Image's strides, RGB the restatement's."""
+    from conftest import SCAN_GROUP_CASES, scan_group_pair
+    lib = J.load_library()
+    data, _ = scan_group_pair(SCAN_GROUP_CASES[1])
+    o = oracle.decode(data)
+    buf = C.create_string_buffer(data, len(data) + 16)
+    fh = _FrameHeader()
+    fh.process = -1
+    img = C.POINTER(_Image)()
+    lib.decode_jpeg_buffer.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(_FrameHeader), C.POINTER(C.POINTER(_Image))]
+    assert lib.decode_jpeg_buffer(buf, len(data), C.byref(fh), C.byref(img)) == 0
+    H, W = o.rgb.shape[:2]
+    for c in range(3):
+        p = o.planes[c]
+        stride = img.contents.width[c]
+        got = np.ctypeslib.as_array(img.contents.buf[c], shape=(p.shape[0], stride))
+        assert np.array_equal(got[:, :p.shape[1]], p), f"Image.buf[{c}] differs"
+    pixels = np.zeros((H, 3 * W), np.uint8)
+    lib.ycbcr_rgb.argtypes = [C.POINTER(_FrameHeader), C.POINTER(_Image), C.c_void_p, C.c_uint16, C.c_uint16, C.c_uint16]
+    assert lib.ycbcr_rgb(C.byref(fh), img, pixels.ctypes.data, W, H, 3 * W) == 0
+    assert np.array_equal(pixels.reshape(H, W, 3), o.rgb)
+    lib.free_img.argtypes = [C.POINTER(_Image)]
+    lib.free_img.restype = None
+    lib.free_img(img)
+    lib.free_frame_header.argtypes = [C.POINTER(_FrameHeader)]
+    lib.free_frame_header(C.byref(fh))
+
+
 def test_no_restart_long_scan_cross_sequence(ctx, oracle):
     """A scan without restart markers that spans many sequences: exercises the
     cross-sequence fix-up and the second write kernel."""

@@ -103,6 +103,51 @@ def test_one_scan_per_component_equals_the_interleaved_coding(oracle, case):
     assert at == m.coefs.shape[0]
 
 
+from conftest import SCAN_GROUP_CASES, scan_group_pair  # noqa: E402
+
+
+@pytest.mark.parametrize("case", SCAN_GROUP_CASES, ids=lambda c: _case_id(c) + "_" + c[6].replace("|", "_"))
+def test_scans_of_some_of_the_components_equal_the_interleaved_coding(oracle, case):
+    """A frame coded in two scans, one component alone and the other two interleaved (T.81 A.2.2,
+    A.2.3).  PARITY UNPINNED against the reference, which has no output for files of several
+    scans (decode.c:125, :473, :504); pinned, like one scan per component, through the
+    interleaved coding of the same quantised coefficients: same RGB, same visible samples, and
+    the same coefficient blocks once they are put in the same order."""
+    multi, inter = scan_group_pair(case)
+    assert multi.count(b"\xff\xda") == 2
+    m, i = oracle.decode(multi), oracle.decode(inter)
+    assert np.array_equal(m.rgb, i.rgb)
+    w, h = case[0], case[1]
+    hs, vs = m.hsf[0], m.vsf[0]
+    assert np.array_equal(m.planes[0][:h, :w], i.planes[0][:h, :w])
+    cw, ch = -(-w // hs), -(-h // vs)
+    for c in (1, 2):
+        assert np.array_equal(m.planes[c][:ch, :cw], i.planes[c][:ch, :cw])
+    mcus_x, mcus_y = i.planes[0].shape[1] // (8 * hs), i.planes[0].shape[0] // (8 * vs)
+    bpm = hs * vs + 2
+    groups = [[0], [1, 2]] if case[6] == "y|cbcr" else [[0, 1], [2]]
+    at = 0
+    for grp in groups:
+        if len(grp) == 1:           # the component's own blocks in raster order
+            c = grp[0]
+            hc, vc = (hs, vs) if c == 0 else (1, 1)
+            base = 0 if c == 0 else hs * vs + c - 1
+            bw, bh = m.planes[c].shape[1] // 8, m.planes[c].shape[0] // 8
+            for by in range(bh):
+                for bx in range(bw):
+                    src = ((by // vc) * mcus_x + bx // hc) * bpm + base + (by % vc) * hc + bx % hc
+                    assert np.array_equal(m.coefs[at], i.coefs[src]), (c, bx, by)
+                    at += 1
+        else:                       # the frame's MCUs with the blocks of the scan's components
+            for mcu in range(mcus_x * mcus_y):
+                for c in grp:
+                    n, base = (hs * vs, 0) if c == 0 else (1, hs * vs + c - 1)
+                    for k in range(n):
+                        assert np.array_equal(m.coefs[at], i.coefs[mcu * bpm + base + k]), (c, mcu, k)
+                        at += 1
+    assert at == m.coefs.shape[0]
+
+
 @pytest.mark.parametrize("name", __import__("conftest").FATAL_FIXTURES)
 def test_fatal_fixture_prefix_equals_the_restatement(oracle, name):
     """Files the compiled reference dies on (its restart check takes a partly consumed data FF

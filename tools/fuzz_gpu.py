@@ -27,8 +27,9 @@ for rnd in range(int(sys.argv[2]) if len(sys.argv) > 2 else 12):
         img = J.synth.synth_image(w, h, seed=int(rng.integers(0, 1 << 30)), sigma=sigma, grey=grey)
         opt = bool(rng.random() < 0.3)
         spc = bool(rng.random() < 0.2) and not grey      # one scan per component
-        data = J.synth.encode_jpeg(img, samp, q, ri, optimise=opt, scans_per_component=spc)
-        files.append(data); meta.append((w, h, samp, q, ri, grey, sigma, opt, spc))
+        grp = None if (grey or spc or rng.random() >= 0.15) else str(rng.choice(["y|cbcr", "ycb|cr"]))     # two scans
+        data = J.synth.encode_jpeg(img, samp, q, ri, optimise=opt, scans_per_component=spc, scans=grp)
+        files.append(data); meta.append((w, h, samp, q, ri, grey, sigma, opt, spc, grp))
     for flags in (0, binding.MJ_ENTROPY_SERIAL):
         b = ctx.batch(files, binding.MJ_WANT_PLANES | flags)
         b.decode(); b.sync()
