@@ -580,6 +580,39 @@ __global__ __launch_bounds__(sync_threads(SYNC_SPW), SYNC_SPW >= 2 ? 5 : 4) void
     }
 }
 
+/* The totals of one sequence's records (blocks completed, DC-difference sums), by one wavefront:
+ * what the prefix over the sequences of a long interval starts from.  Lane 0 parks them in
+ * the sequence's entry; its entry state is filled in by mj_k_entropy_fix once the boundaries
+ * are settled. */
+__device__ __forceinline__ void sequence_totals(const MjSubRec *rec, uint32_t n, uint32_t lane, MjSeqEntry *dst) {
+    uint32_t tnb = 0;
+    int32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    for (uint32_t l = lane; l < n; l += 64) {
+        const MjSubRec r = rec[l];
+        tnb += r.nb;
+        t0 += r.dcsum[0];
+        t1 += r.dcsum[1];
+        t2 += r.dcsum[2];
+        t3 += r.dcsum[3];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        tnb += __shfl_xor(tnb, d, 64);
+        t0 += __shfl_xor(t0, d, 64);
+        t1 += __shfl_xor(t1, d, 64);
+        t2 += __shfl_xor(t2, d, 64);
+        t3 += __shfl_xor(t3, d, 64);
+    }
+    if (lane == 0) {
+        dst->blk = tnb;
+        dst->pred[0] = t0;
+        dst->pred[1] = t1;
+        dst->pred[2] = t2;
+        dst->pred[3] = t3;
+        dst->pad_ = 0;
+    }
+}
+
 /* ------------------------------------------------------------------------ */
 /* kernel 2a: the first cross-sequence pass, spread over the whole chip      */
 /* ------------------------------------------------------------------------ */
@@ -598,31 +631,48 @@ __global__ __launch_bounds__(MJ_WG_SEQS * 64) void mj_k_entropy_fix_first(MjDevi
     const uint32_t n_seq = b.dyn[ii].n_seq;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
     const uint32_t sq0 = ge.y * MJ_WG_SEQS;           /* first sequence (of the image) of the workgroup */
-    /* lane t of every wavefront looks at sequence t, so all wavefronts decide alike whether to stay */
-    const bool some = lane < MJ_WG_SEQS && sq0 + lane < n_seq && b.seq_sub[im.seq_off + sq0 + lane] != 0;
+    /* lane t of every wavefront looks at sequence t, so all wavefronts decide alike whether to stay:
+     * a workgroup has work if any of its sequences belongs to an interval of several */
+    bool some = false;
+    if (lane < MJ_WG_SEQS && sq0 + lane < n_seq) {
+        const uint32_t sub = b.seq_sub[im.seq_off + sq0 + lane];
+        some = sub != 0;
+        if (!some) {
+            const uint32_t SQl = MJ_SEQ_LANES * im.lane_subs;
+            some = interval_geo(b.ivl_start + im.ivl_off, b.seq_ivl[im.seq_off + sq0 + lane], im.sub_bits, SQl).nseq > 1;
+        }
+    }
     if (!__any(some)) return;
     unsigned char *s_pairs = lds_after_dc(b, 0);
     load_tables(b, im, s_pairs, true);
     __syncthreads();
     const uint32_t sq = sq0 + wave;
-    if (sq >= n_seq || b.seq_sub[im.seq_off + sq] == 0) return;
+    if (sq >= n_seq) return;
     const MjScanCtx cx = make_ctx(b, im, s_pairs, true);
     const uint32_t S = im.sub_bits, SQ = MJ_SEQ_LANES * im.lane_subs;
     const uint32_t iv = b.seq_ivl[im.seq_off + sq], first = b.seq_sub[im.seq_off + sq];
     const Geo g = interval_geo(b.ivl_start + im.ivl_off, iv, S, SQ);
+    if (g.nseq <= 1) return;
     MjSubRec *rec = b.rec + im.rec_off + (uint64_t) sq * SQ;       /* this sequence's records; the one before them is the entry */
-    const MjState e = rec[-1].exit;
-    if (lane == 0) b.seq_seen[im.seq_off + sq] = e;
-    uint32_t p = uni(e.p), kc = uni(e.kc);
     const uint32_t n = min(g.nsub - first, (uint32_t) SQ);
-    for (uint32_t l = 0; l < n; l++) {
-        const MjState old = rec[l].exit;
-        const LaneRec o = solo_nowrite(cx, p, kc, sub_end(g.b0, g.b1, g.nsub, first + l, S), lane);
-        if (lane == 0) store_rec(rec + l, o);
-        p = o.p;
-        kc = o.kc;
-        if (uni(old.p) == o.p && uni(old.kc) == o.kc) break;
+    if (lane == 0) b.seq_flag[im.seq_off + sq] = 0;
+    if (first != 0) {
+        const MjState e = rec[-1].exit;
+        if (lane == 0) b.seq_seen[im.seq_off + sq] = e;
+        uint32_t p = uni(e.p), kc = uni(e.kc);
+        for (uint32_t l = 0; l < n; l++) {
+            const MjState old = rec[l].exit;
+            const LaneRec o = solo_nowrite(cx, p, kc, sub_end(g.b0, g.b1, g.nsub, first + l, S), lane);
+            if (lane == 0) store_rec(rec + l, o);
+            p = o.p;
+            kc = o.kc;
+            if (uni(old.p) == o.p && uni(old.kc) == o.kc) break;
+        }
+        __threadfence();        /* lane 0's records, before the other lanes read them */
     }
+    /* the sequence's totals while the chip is at it: mj_k_entropy_fix, one workgroup per interval,
+     * sums again only the sequences it has to decode once more */
+    sequence_totals(rec, n, lane, &b.seq_entry[im.seq_off + sq]);
 }
 
 /* ------------------------------------------------------------------------ */
@@ -658,7 +708,8 @@ __global__ __launch_bounds__(FIX_TPB) void mj_k_entropy_fix(MjDeviceBatch b) {
             const MjState e = rec[(uint64_t) q * SQ - 1].exit;
             const MjState seen = b.seq_seen[seq_first + q];
             const bool redo = e.p != seen.p || e.kc != seen.kc;   /* seen: what mj_k_entropy_fix_first, or the last iteration, started from */
-            b.seq_flag[seq_first + q] = redo ? 1u : 0u;
+            /* bit 0: decode again in this iteration; bit 1: decoded again at some point, so the totals on file are stale */
+            b.seq_flag[seq_first + q] = (b.seq_flag[seq_first + q] & 2u) | (redo ? 3u : 0u);
             if (redo) {
                 b.seq_seen[seq_first + q] = e;
                 s_changed = 1;
@@ -669,7 +720,7 @@ __global__ __launch_bounds__(FIX_TPB) void mj_k_entropy_fix(MjDeviceBatch b) {
         iters++;
         /* one wavefront per boundary that has to be decoded again (solo_nowrite) */
         for (uint32_t q = 1 + (threadIdx.x >> 6); q < g.nseq; q += FIX_TPB / 64) {
-            if (!b.seq_flag[seq_first + q]) continue;
+            if (!(b.seq_flag[seq_first + q] & 1u)) continue;
             const MjState e = b.seq_seen[seq_first + q];
             uint32_t p = uni(e.p), kc = uni(e.kc);
             const uint32_t first = q * SQ;
@@ -691,48 +742,26 @@ __global__ __launch_bounds__(FIX_TPB) void mj_k_entropy_fix(MjDeviceBatch b) {
         atomicMax(&b.stats[MJ_ST_FIXITERS], (unsigned long long) iters);
     }
 
-    /* Prefix over sequences: blocks and DC sums that precede each sequence.  First the
-     * totals of every sequence, one wavefront per sequence at a time (its records are one
-     * contiguous run: coalesced 32-byte loads), parked in the sequence's entry; then an
-     * exclusive scan over the sequences by the whole workgroup. */
+    /* Prefix over sequences: blocks and DC sums that precede each sequence.  The totals of every
+     * sequence are in its entry (mj_k_entropy_fix_first); those of the sequences decoded again here
+     * are summed again, one wavefront per sequence at a time (its records are one contiguous run:
+     * coalesced 32-byte loads); then an exclusive scan over the sequences by the whole workgroup. */
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     for (uint32_t q = wave; q < g.nseq; q += FIX_TPB / 64) {
+        if (!(b.seq_flag[seq_first + q] & 2u)) continue;
         const uint32_t first = q * SQ;
-        const uint32_t n = min(g.nsub - first, (uint32_t) SQ);
-        uint32_t tnb = 0;
-        int32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
-        for (uint32_t l = lane; l < n; l += 64) {
-            const MjSubRec r = rec[(uint64_t) first + l];
-            tnb += r.nb;
-            t0 += r.dcsum[0];
-            t1 += r.dcsum[1];
-            t2 += r.dcsum[2];
-            t3 += r.dcsum[3];
+        sequence_totals(rec + (uint64_t) first, min(g.nsub - first, (uint32_t) SQ), lane, &b.seq_entry[seq_first + q]);
+    }
+    __syncthreads();
+    for (uint32_t q = threadIdx.x; q < g.nseq; q += FIX_TPB) {
+        MjState e;
+        if (q == 0) {
+            e.p = g.b0;
+            e.kc = 0;
+        } else {
+            e = rec[(uint64_t) q * SQ - 1].exit;
         }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            tnb += __shfl_xor(tnb, d, 64);
-            t0 += __shfl_xor(t0, d, 64);
-            t1 += __shfl_xor(t1, d, 64);
-            t2 += __shfl_xor(t2, d, 64);
-            t3 += __shfl_xor(t3, d, 64);
-        }
-        if (lane == 0) {
-            MjSeqEntry se;
-            if (q == 0) {
-                se.entry.p = g.b0;
-                se.entry.kc = 0;
-            } else {
-                se.entry = rec[(uint64_t) q * SQ - 1].exit;
-            }
-            se.blk = tnb;
-            se.pred[0] = t0;
-            se.pred[1] = t1;
-            se.pred[2] = t2;
-            se.pred[3] = t3;
-            se.pad_ = 0;
-            b.seq_entry[seq_first + q] = se;
-        }
+        b.seq_entry[seq_first + q].entry = e;
     }
     __syncthreads();
     const uint32_t blk_base = iv * im.ri * im.bpm;

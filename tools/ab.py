@@ -11,7 +11,7 @@ binding.LIB_PATH = sys.argv[1]
 import bench, torch
 import jpeg_decoder_amd as J
 from jpeg_decoder_amd.shard import shard_seeds
-files = bench.generate(sys.argv[2], shard_seeds(int(os.environ.get("MJ_AB_BATCH", "64")) if sys.argv[2] != "C4" else 4, 0, 1), 16)
+files = bench.generate(sys.argv[2], shard_seeds(int(os.environ.get("MJ_AB_BATCH", "4" if sys.argv[2] == "C4" else "64")), 0, 1), 16)
 ctx = J.Context(0)
 bt = ctx.batch(files, binding.MJ_TIMING)
 for i in range(3):
