@@ -62,7 +62,7 @@ enum {
     MJ_T_ENTROPY = 1,  /* Huffman decode: cold pass + synchronisation rounds (mj_k_entropy_sync) */
     MJ_T_ENTROPY_FIX = 2, /* cross-sequence fix-up (no-RST scans) + the writing pass (mj_k_entropy_fix, _write) */
     MJ_T_IDCT_COLOUR = 3, /* dequant + IDCT + upsample + YCbCr->RGB */
-    MJ_T_MEMSET = 4,   /* zero-fill of the per-decode counters (and of the coefficients in the serial diagnostic mode) */
+    MJ_T_MEMSET = 4,   /* zero-fill of the coefficients in the serial diagnostic mode; else nothing (the counters are cleared by the first scan kernel) */
     MJ_T_COUNT = 5
 };
 

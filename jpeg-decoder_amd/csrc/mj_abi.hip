@@ -989,8 +989,7 @@ int enqueue_decode(mj_batch *b, hipStream_t s) {
     }
 
     HIP_TRY(mark(0));
-    HIP_TRY(hipMemsetAsync(b->d.stats, 0, MJ_ST_COUNT * sizeof(unsigned long long), s));
-    HIP_TRY(hipMemsetAsync(b->d.multi_count, 0, 16, s));
+    /* the per-decode counters are cleared by the first scan kernel */
     if (b->flags & MJ_ENTROPY_SERIAL) {
         /* the diagnostic decoder stores only non-zero coefficients (decode.c:612 zeroes each block first) */
         HIP_TRY(hipMemsetAsync(b->d.coefs, 0, b->coef_bytes ? b->coef_bytes : 16, s));

@@ -580,6 +580,12 @@ __global__ __launch_bounds__(sync_threads(SYNC_SPW), SYNC_SPW >= 2 ? 5 : 4) void
     }
 }
 
+/* intervals of more sequences than this have their sequences' totals summed by mj_k_entropy_fix_first
+ * (one wavefront per sequence, chip-wide) instead of by the interval's one workgroup in mj_k_entropy_fix
+ * (an 8K file without restart markers is a thousand sequences: 0.08 ms of 0.35; files of 18 sequences
+ * lose 6 us to it) */
+constexpr uint32_t FIX_TOTALS_EARLY = 64;
+
 /* The totals of one sequence's records (blocks completed, DC-difference sums), by one wavefront:
  * what the prefix over the sequences of a long interval starts from.  Lane 0 parks them in
  * the sequence's entry; its entry state is filled in by mj_k_entropy_fix once the boundaries
@@ -639,7 +645,7 @@ __global__ __launch_bounds__(MJ_WG_SEQS * 64) void mj_k_entropy_fix_first(MjDevi
         some = sub != 0;
         if (!some) {
             const uint32_t SQl = MJ_SEQ_LANES * im.lane_subs;
-            some = interval_geo(b.ivl_start + im.ivl_off, b.seq_ivl[im.seq_off + sq0 + lane], im.sub_bits, SQl).nseq > 1;
+            some = interval_geo(b.ivl_start + im.ivl_off, b.seq_ivl[im.seq_off + sq0 + lane], im.sub_bits, SQl).nseq > FIX_TOTALS_EARLY;
         }
     }
     if (!__any(some)) return;
@@ -668,11 +674,14 @@ __global__ __launch_bounds__(MJ_WG_SEQS * 64) void mj_k_entropy_fix_first(MjDevi
             kc = o.kc;
             if (uni(old.p) == o.p && uni(old.kc) == o.kc) break;
         }
-        __threadfence();        /* lane 0's records, before the other lanes read them */
     }
-    /* the sequence's totals while the chip is at it: mj_k_entropy_fix, one workgroup per interval,
-     * sums again only the sequences it has to decode once more */
-    sequence_totals(rec, n, lane, &b.seq_entry[im.seq_off + sq]);
+    /* the sequence's totals while the chip is at it, where the interval has so many sequences that
+     * summing them would keep its one workgroup in mj_k_entropy_fix busy for long: that kernel
+     * then sums again only the sequences it has to decode once more */
+    if (g.nseq > FIX_TOTALS_EARLY) {
+        __threadfence();        /* lane 0's records, before the other lanes read them */
+        sequence_totals(rec, n, lane, &b.seq_entry[im.seq_off + sq]);
+    }
 }
 
 /* ------------------------------------------------------------------------ */
@@ -748,7 +757,7 @@ __global__ __launch_bounds__(FIX_TPB) void mj_k_entropy_fix(MjDeviceBatch b) {
      * coalesced 32-byte loads); then an exclusive scan over the sequences by the whole workgroup. */
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     for (uint32_t q = wave; q < g.nseq; q += FIX_TPB / 64) {
-        if (!(b.seq_flag[seq_first + q] & 2u)) continue;
+        if (g.nseq > FIX_TOTALS_EARLY && !(b.seq_flag[seq_first + q] & 2u)) continue;
         const uint32_t first = q * SQ;
         sequence_totals(rec + (uint64_t) first, min(g.nsub - first, (uint32_t) SQ), lane, &b.seq_entry[seq_first + q]);
     }

@@ -80,6 +80,11 @@ __global__ __launch_bounds__(TPB) void mj_k_scan_count(MjDeviceBatch b) {
         s_term = MJ_NO_TERMINATOR;
         s_sum[0] = s_sum[1] = 0;
     }
+    /* the decode's counters start at zero: nothing reads or adds to them before the layout kernel */
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < MJ_ST_COUNT) b.stats[threadIdx.x] = 0ull;
+        if (threadIdx.x < 4) b.multi_count[threadIdx.x] = 0u;
+    }
     __syncthreads();
     MjClass16 cls = {};
     uint32_t w[4];
@@ -311,7 +316,9 @@ __global__ __launch_bounds__(TPB) void mj_k_layout(MjDeviceBatch b) {
     __syncthreads();
     if (!s_last) return;
     __threadfence();
+    __shared__ uint32_t s_img[TPB], s_g[TPB], s_eg[TPB], s_ep[TPB];
     uint32_t carry_g = 0, carry_p = 0;
+    const uint32_t lane = threadIdx.x & 63u;
     for (uint32_t i0 = 0; i0 < b.n_img; i0 += TPB) {
         const uint32_t i = i0 + threadIdx.x;
         uint32_t img = 0, g = 0;
@@ -325,11 +332,29 @@ __global__ __launch_bounds__(TPB) void mj_k_layout(MjDeviceBatch b) {
         uint32_t tg, tp;
         const uint32_t eg = carry_g + block_excl_scan(g, s_w, &tg);
         const uint32_t ep = carry_p + block_excl_scan(p, s_w, &tp);
-        for (uint32_t k = 0; k < g; k++) {
-            if (eg + k < b.n_entropy_wg) b.grp_list[eg + k] = make_uint2(img, k);
+        /* an image of a few groups is listed by its own thread; one of many (a file without
+         * restart markers may have a thousand) by a wavefront, a lane per entry */
+        constexpr uint32_t OWN = 48;
+        if (g <= OWN) {
+            for (uint32_t k = 0; k < g; k++) {
+                if (eg + k < b.n_entropy_wg) b.grp_list[eg + k] = make_uint2(img, k);
+                if (!(k & 1u) && ep + (k >> 1) < b.n_sync_pairs) b.pair_list[ep + (k >> 1)] = make_uint2(img, k);
+            }
         }
-        for (uint32_t k = 0; k < p; k++) {
-            if (ep + k < b.n_sync_pairs) b.pair_list[ep + k] = make_uint2(img, 2 * k);
+        const unsigned long long big = __ballot(g > OWN);
+        if (big) {
+            s_img[threadIdx.x] = img;
+            s_g[threadIdx.x] = g;
+            s_eg[threadIdx.x] = eg;
+            s_ep[threadIdx.x] = ep;
+            for (unsigned long long m = big; m; m &= m - 1) {          /* this wavefront's own large images, one after the other */
+                const uint32_t t = (threadIdx.x & ~63u) + (uint32_t) __builtin_ctzll(m);
+                const uint32_t gi = s_g[t], im_i = s_img[t], eg_i = s_eg[t], ep_i = s_ep[t];
+                for (uint32_t k = lane; k < gi; k += 64) {
+                    if (eg_i + k < b.n_entropy_wg) b.grp_list[eg_i + k] = make_uint2(im_i, k);
+                    if (!(k & 1u) && ep_i + (k >> 1) < b.n_sync_pairs) b.pair_list[ep_i + (k >> 1)] = make_uint2(im_i, k);
+                }
+            }
         }
         carry_g += tg;
         carry_p += tp;
@@ -343,7 +368,12 @@ __global__ __launch_bounds__(TPB) void mj_k_layout(MjDeviceBatch b) {
 }  // namespace
 
 hipError_t mj_launch_scan(const MjDeviceBatch &b, hipStream_t s) {
-    if (b.n_tiles == 0 || b.n_img == 0) return hipSuccess;
+    if (b.n_tiles == 0 || b.n_img == 0) {
+        /* nothing to scan: the counters the first scan kernel would have cleared */
+        hipError_t e = hipMemsetAsync(b.stats, 0, MJ_ST_COUNT * sizeof(unsigned long long), s);
+        if (e == hipSuccess) e = hipMemsetAsync(b.multi_count, 0, 16, s);
+        return e;
+    }
     hipLaunchKernelGGL(mj_k_scan_count, dim3(b.n_tiles), dim3(TPB), 0, s, b);
     hipLaunchKernelGGL(mj_k_scan_prefix, dim3(b.n_img), dim3(TPB), 0, s, b);
     hipLaunchKernelGGL(mj_k_scan_write, dim3(b.n_tiles), dim3(TPB), 0, s, b);
