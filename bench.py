@@ -447,6 +447,9 @@ def main():
                          "sub-batches overlap; per-kernel times then include the overlap)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher, placement and reduction wiring only: no GPU, no decode, gloo instead of RCCL")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="every rank decodes on GPU 0 and the reductions go over gloo: the whole N-rank flow on a box with one GPU "
+                         "(RCCL refuses two ranks on one device); the rates it prints are those of ranks sharing a GPU")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -537,11 +540,14 @@ def main():
     from jpeg_decoder_amd import binding
 
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
-    torch.cuda.set_device(local_rank)
+    rehearsal = args.rehearse_on_one_gpu and world > 1
+    dev_index = 0 if rehearsal else local_rank
+    red_dev = "cpu" if rehearsal else "cuda"          # where the reductions' few numbers live: gloo reduces on the host
+    torch.cuda.set_device(dev_index)
     # the placement once more, now from the PCI addresses the runtime reports for the local GPUs
     try:
         n_dev = torch.cuda.device_count()
-        bdfs = [binding.device_pci_bus_id(r) if r < n_dev else None for r in range(local_world)]
+        bdfs = [binding.device_pci_bus_id(0 if rehearsal else r) if (rehearsal or r < n_dev) else None for r in range(local_world)]
         sure = topology.plan(local_rank, local_world, allowed0, bdfs=bdfs, source="pci")
         if sure.source == "split":
             sure.source = "pci, split"
@@ -555,7 +561,10 @@ def main():
     except RuntimeError as e:
         place.note = (place.note + "; " if place.note else "") + f"PCI address not available: {e}"
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     def barrier():
         torch.cuda.synchronize()
@@ -567,7 +576,7 @@ def main():
 
     # ---- region 1: compressed bytes resident in HBM ---------------------------------
     n_streams = max(1, min(args.streams, len(files)))
-    ctxs = [J.Context(local_rank) for _ in range(n_streams)]       # one HIP stream each
+    ctxs = [J.Context(dev_index) for _ in range(n_streams)]       # one HIP stream each
     t0 = time.perf_counter()
     batches = [ctxs[i].batch(files[i::n_streams], flags) for i in range(n_streams)]
     t_prepare_first = time.perf_counter() - t0      # host parse + table flattening + allocation + H2D of the compressed bytes
@@ -648,7 +657,7 @@ def main():
     sustained = None
     t_pinned = None
     if not args.no_pipeline:
-        ctx = J.Context(local_rank)
+        ctx = J.Context(dev_index)
         t_pinned = time.monotonic()                  # the first page-locked input buffer is made here, after the placement
         pinned = [binding.PinnedFiles(fs) for fs in file_sets]
         depth = max(2, min(args.depth, 8))
@@ -730,15 +739,15 @@ def main():
     # ---- one reduction per region (SUM of the counters, MAX of the times) + the per-rank figures
     knames = sorted(kms)
     tot = reduce_run(pixels_rank, args.batch, comp_bytes_rank, float(mismatched), elapsed,
-                     [kms[k][0] / max(kms[k][1], 1) for k in knames], device="cuda")
+                     [kms[k][0] / max(kms[k][1], 1) for k in knames], device=red_dev)
     total_pixels, total_images = tot.pixels, tot.images
     elapsed_max = tot.elapsed_max
     kernel_ms_max = dict(zip(knames, tot.kernel_ms_max))
     ptot = stot = None
     if pipe_res is not None:
-        ptot = reduce_run(pipe_res["pixels"], 0.0, 0.0, 0.0, pipe_res["elapsed"], [pipe_res["host_submit_ms"]], device="cuda")
+        ptot = reduce_run(pipe_res["pixels"], 0.0, 0.0, 0.0, pipe_res["elapsed"], [pipe_res["host_submit_ms"]], device=red_dev)
     if sustained is not None:
-        stot = reduce_run(sustained["pixels"], float(sustained["submits"]), 0.0, 0.0, sustained["elapsed"], [0.0], device="cuda")
+        stot = reduce_run(sustained["pixels"], float(sustained["submits"]), 0.0, 0.0, sustained["elapsed"], [0.0], device=red_dev)
     rows = gather_ranks([
         pixels_rank * args.steps / elapsed / 1e6,
         pipe_res["pixels"] / pipe_res["elapsed"] / 1e6 if pipe_res else 0.0,
@@ -746,7 +755,7 @@ def main():
         place.numa_node, len(place.cpus),
         sustained["pixels"] / sustained["elapsed"] / 1e6 if sustained else 0.0,
         1.0 if (place.applied and t_pinned is not None and t_affinity < t_pinned) else 0.0,
-        args.batch], device="cuda")
+        args.batch], device=red_dev)
 
     if rank == 0:
         resident_value = total_pixels * args.steps / elapsed_max / 1e6
@@ -792,7 +801,7 @@ def main():
                        "images_per_gpu": args.batch, "global_batch": int(total_images),
                        "compressed_MB_per_gpu": round(comp_bytes_rank / 1e6, 1),
                        "bits_per_pixel": round(8.0 * comp_bytes_rank / pixels_rank, 3),
-                       "parallelism": f"image-sharded x{world}, no data-path collective",
+                       "parallelism": f"image-sharded x{world}, no data-path collective" + (" (REHEARSAL: all ranks on GPU 0, gloo)" if rehearsal else ""),
                        "entropy_mode": "serial (diagnostic)" if args.serial_entropy else "subsequence-sync",
                        "streams": n_streams},
             "resident": {"value": round(resident_value, 1), "unit": "MP/s", "ms_per_step": round(resident_ms, 4),

@@ -38,3 +38,24 @@ def test_bench_line_on_one_gpu():
     assert s["seconds"] >= 0.5 and s["submits"] >= 3 and s["MPps"] > 0 and 0.2 < s["ratio_to_value"] < 5
     # a traffic figure only with its provenance; C1 x 16 has no counter pass on file
     assert out["roofline"]["traffic"] is None and "why_null" in out["roofline"]["traffic_source"]
+
+
+def test_two_ranks_rehearsed_on_one_gpu():
+    """The N-rank flow end to end on the one GPU of the box: two ranks (started by bench.py
+    itself) generate disjoint inputs, place themselves on disjoint CPUs, decode on GPU 0 and
+    reduce over gloo; rank 0 prints the job's line with the per-rank arrays in rank order."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--workload", "C1",
+                        "--batch", "8", "--steps", "3", "--warmup", "1", "--sustain-seconds", "0.3", "--gen-workers", "2"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 16 and "REHEARSAL" in out["config"]["parallelism"]
+    assert out["images_per_rank"] == [8, 8] and out["affinity_before_pinned_alloc_per_rank"] == [1, 1]
+    assert out["parity_mismatches_all_ranks"] == 0
+    assert all(v > 0 for k in ("pinned_MPps_per_rank", "resident_MPps_per_rank", "sustained_MPps_per_rank") for v in out[k])
+    # the job's rate is all ranks' pixels over the slowest rank's time: no more than the sum of the ranks' own rates
+    assert out["value"] <= 1.02 * sum(out["pinned_MPps_per_rank"])
+    assert "cpu_baseline" not in out              # rank 0 of one GPU only
