@@ -59,3 +59,32 @@ def test_two_ranks_rehearsed_on_one_gpu():
     # the job's rate is all ranks' pixels over the slowest rank's time: no more than the sum of the ranks' own rates
     assert out["value"] <= 1.02 * sum(out["pinned_MPps_per_rank"])
     assert "cpu_baseline" not in out              # rank 0 of one GPU only
+
+
+def test_rccl_reduction_with_one_rank_on_the_gpu():
+    """The end-of-run reduction and the per-rank gather over RCCL (backend "nccl") on device
+    tensors: a world of one rank on the box's GPU (more ranks than GPUs is not something RCCL
+    accepts); what N ranks run is the same two collectives."""
+    code = r'''
+import os, sys, json
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from jpeg_decoder_amd.shard import reduce_run, gather_ranks
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29731", RANK="0", WORLD_SIZE="1")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+t = reduce_run(100.0, 2.0, 30.0, 1.0, 0.5, [1.0, 2.0], device="cuda")
+rows = gather_ranks([7.0, 8.0, 9.0], device="cuda")
+# world of one: force the collectives themselves as well
+x = torch.tensor([1.0, 2.0], dtype=torch.float64, device="cuda")
+dist.all_reduce(x, op=dist.ReduceOp.SUM)
+out = [torch.empty_like(x)]
+dist.all_gather(out, x)
+dist.barrier()
+dist.destroy_process_group()
+print(json.dumps({"pixels": t.pixels, "elapsed": t.elapsed_max, "kernels": t.kernel_ms_max, "rows": rows, "x": x.tolist(), "g": out[0].tolist()}))
+''' % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out == {"pixels": 100.0, "elapsed": 0.5, "kernels": [1.0, 2.0], "rows": [[7.0, 8.0, 9.0]], "x": [1.0, 2.0], "g": [1.0, 2.0]}
