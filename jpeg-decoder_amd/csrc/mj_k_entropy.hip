@@ -692,9 +692,12 @@ constexpr int FIX_TPB = 1024;
 __global__ __launch_bounds__(FIX_TPB) void mj_k_entropy_fix(MjDeviceBatch b) {
     __shared__ int s_changed;
     __shared__ uint32_t s_part[FIX_TPB / 64];
+    /* the grid is a bound (the host does not know how many intervals take several sequences): a
+     * workgroup takes the entries blockIdx.x, blockIdx.x + gridDim.x, ... of the list */
     const uint32_t n_multi = min(*b.multi_count, b.n_multi_cap);
-    if (blockIdx.x >= n_multi) return;
-    const uint2 mi = b.multi[blockIdx.x];
+    for (uint32_t entry = blockIdx.x; entry < n_multi; entry += gridDim.x) {
+    __syncthreads();            /* the last entry's uses of the shared words and tables are over */
+    const uint2 mi = b.multi[entry];
     const MjImageDev &im = b.img[mi.x];
     const uint32_t iv = mi.y;
     const uint32_t S = im.sub_bits, SQ = MJ_SEQ_LANES * im.lane_subs;
@@ -815,6 +818,7 @@ __global__ __launch_bounds__(FIX_TPB) void mj_k_entropy_fix(MjDeviceBatch b) {
             b.seq_entry[seq_first + q].pred[3] = (int32_t) v[4];
         }
     }
+    }   /* entries */
 }
 
 /* ------------------------------------------------------------------------ */
@@ -1027,7 +1031,10 @@ hipError_t mj_launch_entropy(const MjDeviceBatch &b, hipStream_t s) {
 hipError_t mj_launch_entropy_fix(const MjDeviceBatch &b, hipStream_t s) {
     if (b.n_multi_cap == 0 || b.n_entropy_wg == 0) return hipSuccess;
     hipLaunchKernelGGL(mj_k_entropy_fix_first, dim3(b.n_entropy_wg), dim3(MJ_WG_SEQS * 64), table_lds(b, 0) + (size_t) b.max_nac * sizeof(MjHuffRun), s, b);
-    hipLaunchKernelGGL(mj_k_entropy_fix, dim3(b.n_multi_cap), dim3(FIX_TPB),
+    uint32_t cus = 0;
+    const hipError_t e = mj_device_cus(&cus);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(mj_k_entropy_fix, dim3(b.n_multi_cap < 2 * cus ? b.n_multi_cap : 2 * cus), dim3(FIX_TPB),
                        table_lds(b, 0) + (size_t) b.max_nac * sizeof(MjHuffRun), s, b);
     return hipGetLastError();
 }
