@@ -15,7 +15,7 @@
 #define MJ_LUT_SIZE (1 << MJ_LUT_BITS)
 #define MJ_SEQ_LANES 64        /* lanes per wavefront; a sequence is MJ_SEQ_LANES * lane_subs subsequences */
 #define MJ_MAX_LANE_SUBS 8
-#define MJ_SCAN_TILE 4096      /* raw bytes per scan-kernel workgroup */
+#define MJ_SCAN_TILE 8192      /* raw bytes per scan-kernel workgroup (a multiple of 4096) */
 #define MJ_STREAM_PAD 64       /* readable zero bytes after every compacted stream */
 #define MJ_NO_TERMINATOR 0xFFFFFFFFu
 

@@ -22,7 +22,8 @@
 namespace {
 
 constexpr int TPB = 256;
-static_assert(TPB * 16 == MJ_SCAN_TILE, "one thread per 16 raw bytes");
+constexpr int GR = MJ_SCAN_TILE / (TPB * 16);     /* groups of sixteen consecutive raw bytes per thread */
+static_assert(GR >= 1 && TPB * 16 * GR == MJ_SCAN_TILE, "a thread takes whole groups of 16 raw bytes");
 
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
     const int lane = threadIdx.x & 63;
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(TPB) void mj_k_scan_count(MjDeviceBatch b) {
     const MjImageDev &im = b.img[ii];
     const uint32_t len = (uint32_t) im.raw_len;
     const uint8_t *seg = b.raw + im.raw_off;
-    const uint32_t pos = (tile - im.tile_off) * MJ_SCAN_TILE + threadIdx.x * 16;
+    const uint32_t pos0 = (tile - im.tile_off) * MJ_SCAN_TILE + threadIdx.x * (16 * GR);
     if (threadIdx.x == 0) {
         s_term = MJ_NO_TERMINATOR;
         s_sum[0] = s_sum[1] = 0;
@@ -86,22 +87,33 @@ __global__ __launch_bounds__(TPB) void mj_k_scan_count(MjDeviceBatch b) {
         if (threadIdx.x < 4) b.multi_count[threadIdx.x] = 0u;
     }
     __syncthreads();
-    MjClass16 cls = {};
-    uint32_t w[4];
+    MjClass16 cls[GR];
     uint32_t my_term = MJ_NO_TERMINATOR;
-    if (pos < len) {
-        cls = mj_classify16_at(seg, len, pos, w);
-        /* first terminating marker in the tile */
 #pragma unroll
-        for (int i = 3; i >= 0; i--) {
-            if (cls.term[i]) my_term = pos + 4 * i + ((uint32_t) __builtin_ctz(cls.term[i]) >> 3);
+    for (int g = GR - 1; g >= 0; g--) {
+        const uint32_t pos = pos0 + 16 * g;
+        cls[g] = MjClass16{};
+        if (pos < len) {
+            uint32_t w[4];
+            cls[g] = mj_classify16_at(seg, len, pos, w);
+            /* first terminating marker in the tile */
+#pragma unroll
+            for (int i = 3; i >= 0; i--) {
+                if (cls[g].term[i]) my_term = pos + 4 * i + ((uint32_t) __builtin_ctz(cls[g].term[i]) >> 3);
+            }
         }
     }
     if (my_term != MJ_NO_TERMINATOR) atomicMin(&s_term, my_term);
     __syncthreads();
     const uint32_t term = s_term;
-    uint32_t kept, rst;
-    cut_at(cls, pos, term, kept, rst);
+    uint32_t kept = 0, rst = 0;
+#pragma unroll
+    for (int g = 0; g < GR; g++) {
+        uint32_t k1, r1;
+        cut_at(cls[g], pos0 + 16 * g, term, k1, r1);
+        kept += k1;
+        rst += r1;
+    }
     /* block sums: wave reduce then LDS atomics (4 waves) */
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -182,12 +194,21 @@ __global__ __launch_bounds__(TPB) void mj_k_scan_write(MjDeviceBatch b) {
     if (tile_pos >= term) return; /* whole block: nothing of this tile survives */
     const uint32_t len = (uint32_t) im.raw_len;
     const uint8_t *seg = b.raw + im.raw_off;
-    const uint32_t pos = tile_pos + threadIdx.x * 16;
-    MjClass16 cls = {};
-    uint32_t w[4] = {0, 0, 0, 0};
-    if (pos < len) cls = mj_classify16_at(seg, len, pos, w);
-    uint32_t kept, rst;
-    cut_at(cls, pos, term, kept, rst);
+    const uint32_t pos0 = tile_pos + threadIdx.x * (16 * GR);
+    MjClass16 cls[GR];
+    uint32_t w[GR][4];
+    uint32_t kept = 0, rst = 0;
+#pragma unroll
+    for (int g = 0; g < GR; g++) {
+        const uint32_t pos = pos0 + 16 * g;
+        cls[g] = MjClass16{};
+        w[g][0] = w[g][1] = w[g][2] = w[g][3] = 0;
+        if (pos < len) cls[g] = mj_classify16_at(seg, len, pos, w[g]);
+        uint32_t k1, r1;
+        cut_at(cls[g], pos, term, k1, r1);
+        kept += k1;
+        rst += r1;
+    }
     uint32_t total;
     const uint32_t ex = block_excl_scan(kept | (rst << 16), s_w, &total);
     const MjTileBase tb = b.tile_base[tile];
@@ -199,13 +220,16 @@ __global__ __launch_bounds__(TPB) void mj_k_scan_write(MjDeviceBatch b) {
     if (kept | rst) {
         uint32_t *ivl = b.ivl_start + im.ivl_off;
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const uint32_t bit = 1u << (8 * (i & 3) + 7);
-            if (cls.keep[i >> 2] & bit) {
-                s_out[out++] = (uint8_t) ((w[i >> 2] >> (8 * (i & 3))) & 0xFFu);
-            } else if (cls.rst[i >> 2] & bit) {
-                ridx++;
-                if (ridx < im.n_ivl) ivl[ridx] = out0 - skew + out; /* interval ridx starts at the next surviving byte */
+        for (int g = 0; g < GR; g++) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const uint32_t bit = 1u << (8 * (i & 3) + 7);
+                if (cls[g].keep[i >> 2] & bit) {
+                    s_out[out++] = (uint8_t) ((w[g][i >> 2] >> (8 * (i & 3))) & 0xFFu);
+                } else if (cls[g].rst[i >> 2] & bit) {
+                    ridx++;
+                    if (ridx < im.n_ivl) ivl[ridx] = out0 - skew + out; /* interval ridx starts at the next surviving byte */
+                }
             }
         }
     }
