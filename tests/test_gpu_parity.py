@@ -515,6 +515,55 @@ def test_colour_entry_points_convert_the_planes_they_are_given(ctx, name, hsf, v
     lib.free_img(img)
 
 
+@pytest.mark.parametrize("sf", [((1, 1), (1, 1), (1, 1)), ((2, 2), (1, 1), (1, 1)), ((3, 1), (1, 1), (1, 1)), ((4, 2), (2, 1), (1, 2)),
+                                ((3, 3), (1, 3), (3, 1)), ((2, 4), (1, 1), (2, 2)), ((4, 4), (1, 1), (1, 1))])
+@pytest.mark.parametrize("size", [(37, 23), (256, 64), (1001, 5)])
+def test_planes_to_rgb_at_any_sampling_factors(ctx, oracle, sf, size):
+    """mj_planes_to_rgb against the reference's indexing and arithmetic (colour_conversion.c:44-79:
+    source sample (uint32)(ratio * i) with ratio = (float) sf / max_sf; the colour step through the
+    restatement) for sampling factors the decode path itself never produces, 3 included, where the
+    float product decides which sample a pixel takes."""
+    lib = J.load_library()
+    W, H = size
+    hs, vs = [f[0] for f in sf], [f[1] for f in sf]
+    hm, vm = max(hs), max(vs)
+    rng = np.random.default_rng(W * 7 + H + hs[0] * 100 + vs[0])
+    planes, strides = [], []
+    for c in range(3):
+        x, y = -(-W * hs[c] // hm), -(-H * vs[c] // vm)
+        pw = -(-x // (8 * hs[c])) * 8 * hs[c]
+        ph = -(-y // (8 * vs[c])) * 8 * vs[c]
+        planes.append(rng.integers(0, 256, (ph, pw), dtype=np.uint8))
+        strides.append(pw)
+    # the reference's loops in numpy: float32 ratios, float32 products, truncation
+    i = np.arange(H, dtype=np.float32)
+    j = np.arange(W, dtype=np.float32)
+    comp = []
+    for c in range(3):
+        hr, vr = np.float32(hs[c]) / np.float32(hm), np.float32(vs[c]) / np.float32(vm)
+        rows = (i * vr).astype(np.uint32)
+        cols = (hr * j).astype(np.uint32)
+        comp.append(planes[c][rows][:, cols])
+    want = oracle.ycbcr_row(comp[0].ravel(), comp[1].ravel(), comp[2].ravel()).reshape(H, W, 3)
+    pitch = 3 * W + 5
+    out = np.zeros((H, pitch), np.uint8)
+    lib.mj_planes_to_rgb.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                     C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+    pp = (C.c_void_p * 3)(*[p.ctypes.data for p in planes])
+    rc = lib.mj_planes_to_rgb(ctx.h, 3, pp, (C.c_int32 * 3)(*strides), (C.c_int32 * 3)(*hs), (C.c_int32 * 3)(*vs), W, H,
+                              out.ctypes.data, pitch)
+    assert rc == 0, lib.mj_last_error()
+    assert np.array_equal(out[:, :3 * W].reshape(H, W, 3), want)
+    assert not out[:, 3 * W:].any()
+    # one component: R = G = B at the stride given
+    grey = np.zeros((H, 3 * W), np.uint8)
+    rc = lib.mj_planes_to_rgb(ctx.h, 1, pp, (C.c_int32 * 3)(*strides), (C.c_int32 * 3)(1, 1, 1), (C.c_int32 * 3)(1, 1, 1), min(W, strides[0]),
+                              min(H, planes[0].shape[0]), grey.ctypes.data, 3 * W)
+    assert rc == 0
+    w1, h1 = min(W, strides[0]), min(H, planes[0].shape[0])
+    assert np.array_equal(grey.reshape(H, W, 3)[:h1, :w1], np.repeat(planes[0][:h1, :w1, None], 3, 2))
+
+
 def test_colour_entry_point_sees_planes_edited_after_the_decode(ctx, oracle):
     lib = J.load_library()
     data, g = load_fixture("c420_q85_100x75_ri3")
