@@ -16,11 +16,13 @@
  *   - grey output reads the padded plane with its real stride
  *     (colour_conversion.c:20 strides by the image width).
  *
- * Files whose three-component frame is coded in several scans (one component each, or one alone
- * and two together: T.81 A.2.2, A.2.3, B.2.3) are decoded by orc_run_scans below.  PARITY UNPINNED for that path: the reference re-enters its
- * scan loop without resetting its MCU counter (decode.c:125, :473, :504) and writes past its
- * planes, so it has no output to be equal to; the tests pin this path instead against the
- * interleaved coding of the same coefficients, which the reference does decode.
+ * Files whose three-component frame is coded in several scans (one component each,
+ * or one alone and two together: T.81 A.2.2, A.2.3, B.2.3) are decoded by
+ * orc_run_scans below.  PARITY UNPINNED for that path: the reference re-enters its
+ * scan loop without resetting its MCU counter (decode.c:125, :473, :504) and writes
+ * past its planes, so it has no output to be equal to; the tests pin this path
+ * instead against the interleaved coding of the same coefficients, which the
+ * reference does decode.
  *
  * Build with -ffp-contract=off: the float/double rounding points below are the
  * reference's (gcc -std=c17 -O2 on x86-64, FLT_EVAL_METHOD 0, no FMA contraction).
