@@ -59,7 +59,7 @@ typedef struct {
 /* kernel slots reported by mj_batch_kernel_ms (MJ_TIMING) */
 enum {
     MJ_T_SCAN = 0,     /* unstuff + restart-marker discovery + subsequence layout */
-    MJ_T_ENTROPY = 1,  /* Huffman decode: cold pass + synchronisation rounds (mj_k_entropy_sync) */
+    MJ_T_ENTROPY = 1,  /* Huffman decode: cold pass + synchronisation rounds (mj_k_entropy_sync), or the speculative form (mj_k_spec_*) */
     MJ_T_ENTROPY_FIX = 2, /* cross-sequence fix-up (no-RST scans) + the writing pass (mj_k_entropy_fix, _write) */
     MJ_T_IDCT_COLOUR = 3, /* dequant + IDCT + upsample + YCbCr->RGB */
     MJ_T_MEMSET = 4,   /* zero-fill of the coefficients in the serial diagnostic mode; else nothing (the counters are cleared by the first scan kernel) */
@@ -81,6 +81,17 @@ int mj_set_stream(mj_ctx *ctx, void *hip_stream);
  * thread on one CPU (jpeg_decoder.c:29-112); a process per GPU uses it to put itself and
  * its page-locked buffers on the GPU's side of the host before it allocates them. */
 int mj_device_pci_bus_id(int device, char *buf, size_t cap);
+/* How the batches built from now on (process-wide) bring the lanes of the Huffman decode into
+ * step -- the part of decode_scan (decode.c:535-663) that a serial decoder does not have.
+ * mode 0: the library chooses by the size of the batch (the default); 1: always the
+ * synchronisation rounds; 2: always the speculative form (every lane decoded once per block
+ * slot of the MCU and a little further, the true decode looked up: several times the work, no
+ * serial chain -- what a batch that leaves the chip idle gets by itself).  sub_bits, lane_subs
+ * (1, 2, 4 or 8) and extra (subsequences a lane decodes past its own, 1 or more) are the
+ * parameters of the speculative form; 0 leaves each to the library.  The results are the same
+ * bit for bit whatever is set here; returns 0, or -1 for values outside those ranges.  No
+ * counterpart in the reference; for callers that know their workload, and for the tests. */
+int mj_set_sync_policy(int mode, int sub_bits, int lane_subs, int extra);
 
 /* Parse n baseline JPEG files with the host parsers (decode_frame_header,
  * decode_huff_tables, decode_quant_table, decode_restart_interval,
@@ -212,7 +223,9 @@ int mj_batch_reset_timing(mj_batch *b);
 /* Entropy-stage statistics of the last decode (device counters, read back):
  * [0] subsequences, [1] synchronisation rounds summed over workgroups, [2] max rounds
  * in a workgroup, [3] sequences, [4] multi-sequence intervals, [5] fix-up iterations,
- * [6] subsequence decodes spent in the rounds, [7] workgroups that ran. */
+ * [6] subsequence decodes spent in the rounds, [7] workgroups that ran.  A batch that took the
+ * speculative form (mj_set_sync_policy) has no rounds: [7] and [2] are 0, [1] counts the hops of
+ * the true chain that were guesses and [6] the subsequences decoded again from them. */
 int mj_batch_entropy_stats(mj_batch *b, int64_t stats[8]);
 
 #ifdef __cplusplus

@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "mj_batch_decode", "mj_batch_sync", "mj_batch_size", "mj_batch_image_info", "mj_batch_status",
     "mj_batch_device_rgb", "mj_batch_device_coefs", "mj_batch_copy_rgb", "mj_batch_copy_coefs",
     "mj_batch_copy_plane", "mj_batch_kernel_ms", "mj_batch_reset_timing", "mj_batch_entropy_stats",
-    "mj_host_alloc", "mj_host_free", "mj_pipe_create", "mj_pipe_submit", "mj_pipe_destroy", "mj_pipe_host_ms", "mj_decode_static", "mj_planes_to_rgb", "mj_set_scan_limit",
+    "mj_host_alloc", "mj_host_free", "mj_pipe_create", "mj_pipe_submit", "mj_pipe_destroy", "mj_pipe_host_ms", "mj_decode_static", "mj_planes_to_rgb", "mj_set_scan_limit", "mj_set_sync_policy",
 ]
 COMPAT_SYMBOLS = [
     "get_byte", "next_byte", "next_bit", "next_bit_size", "check_marker", "next_byte_restart_marker", "progress",
@@ -69,6 +69,7 @@ def load_library():
     lib.mj_destroy.restype = None
     lib.mj_set_stream.argtypes = [vp, vp]
     lib.mj_device_pci_bus_id.argtypes = [i32, C.c_char_p, C.c_size_t]
+    lib.mj_set_sync_policy.argtypes = [i32, i32, i32, i32]
     lib.mj_batch_create.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), i32, u32, C.POINTER(vp)]
     lib.mj_batch_destroy.argtypes = [vp]
     lib.mj_batch_destroy.restype = None
@@ -106,6 +107,15 @@ def _check(lib, rc, what):
     if rc != 0:
         msg = lib.mj_last_error()
         raise RuntimeError(f"{what} failed ({rc}): {msg.decode() if msg else '?'}")
+
+
+SYNC_AUTO, SYNC_ROUNDS, SYNC_SPECULATIVE = 0, 1, 2
+
+
+def set_sync_policy(mode=SYNC_AUTO, sub_bits=0, lane_subs=0, extra=0):
+    """How the batches built from now on synchronise their lanes (process-wide); same results either way."""
+    lib = load_library()
+    _check(lib, lib.mj_set_sync_policy(mode, sub_bits, lane_subs, extra), "mj_set_sync_policy")
 
 
 def device_pci_bus_id(device):
@@ -366,12 +376,14 @@ class Emu:
         self.lib.mj_emu_ycbcr_row(y.ctypes.data, cb.ctypes.data, cr.ctypes.data, y.size, out.ctypes.data)
         return out
 
-    def decode_coefs(self, data, n_blocks_cap, sub_bits=0, lane_subs=0):
+    def decode_coefs(self, data, n_blocks_cap, sub_bits=0, lane_subs=0, spec_x=0):
+        """spec_x > 0: the speculative synchronisation with that many extra subsequences per lane."""
         out = np.zeros((n_blocks_cap, 64), np.int16)
         st = (C.c_int64 * 16)()
-        n = self.lib.mj_emu_decode_coefs(data, len(data), out.ctypes.data, n_blocks_cap, sub_bits | (lane_subs << 16), st)
+        n = self.lib.mj_emu_decode_coefs(data, len(data), out.ctypes.data, n_blocks_cap,
+                                         sub_bits | (lane_subs << 16) | (spec_x << 24), st)
         if n < 0:
             raise RuntimeError("mj_emu_decode_coefs failed")
         keys = ["subsequences", "rounds_sum", "rounds_max", "sequences", "multi_seq_intervals", "fix_iterations",
-                "sub_bits", "n_rst", "lane_subs", "round_tasks"]
+                "sub_bits", "n_rst", "lane_subs", "round_tasks", "spec_guesses", "spec_mended", "spec_mended_max"]
         return out[:n], dict(zip(keys, [int(v) for v in st]))

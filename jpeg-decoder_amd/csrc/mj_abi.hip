@@ -32,6 +32,7 @@
 #include "../host/mj_host.h"
 #include "mi355jpeg.h"
 #include "mj_internal.h"
+#include "mj_spec_core.h"
 
 /* Work memory of mj_decode_static: one copy per GPU, held from the moment the library's
  * code is loaded on that GPU until the process ends.  In host code this name is only a
@@ -75,6 +76,28 @@ constexpr int kCopyStreams = 1;
 
 constexpr size_t kStaticMetaBytes = 4u << 20;   /* page-locked mirror of the meta region of mj_decode_static */
 
+/* How batches choose between the rounds and the speculative synchronisation (mj_set_sync_policy). */
+#ifndef MJ_SPEC_MAX_WORK_BITS_PER_CU
+#define MJ_SPEC_MAX_WORK_BITS_PER_CU 2050000u   /* 0.52 Gbit of counting decode on 256 CUs: about a fifth of a millisecond */
+#endif
+#ifndef MJ_SPEC_LONG_INTERVAL_BITS
+#define MJ_SPEC_LONG_INTERVAL_BITS 262144u
+#endif
+#ifndef MJ_SPEC_SUB_BITS
+#define MJ_SPEC_SUB_BITS 256u
+#endif
+/* Subsequences a lane decodes past its own, by lane_subs: what matters is that a lane's
+ * variants have some 768 bits in which to fall into step before the trajectory of the lane
+ * before them ends, and the more lanes start, the more chances there are (counted on 512 x 512
+ * files at 2 bit per pixel: lanes of one subsequence and three more never had to guess, lanes
+ * of two and three more once in four files, lanes of four and four more once or twice a file). */
+static inline uint32_t spec_default_extra(uint32_t lane_subs) {
+    return lane_subs <= 2 ? 3u : 4u;
+}
+struct SyncPolicy {
+    uint32_t mode = 0, sub_bits = 0, lane_subs = 0, extra = 0;
+} g_sync;
+
 /* offsets of every device buffer inside its region (all multiples of 256) */
 struct Offsets {
     /* meta */
@@ -83,7 +106,7 @@ struct Offsets {
     size_t dyn, tile_cnt, tile_base, ivl_start, ivl_seq, seq_ivl, seq_sub, seq_entry, seq_seen, seq_flag, multi, multi_count,
         grp_list, pair_list, stats, state_bytes;
     /* work */
-    size_t raw, cmp, rec, work_bytes;
+    size_t raw, cmp, rec, spec_rec, spec_map, spec_tot, spec_brk, work_bytes;
     /* out */
     size_t coefs, rgb, planes, out_bytes;
 };
@@ -611,7 +634,7 @@ MjIdctImg idct_record(const MjImageDev &im, uint32_t first_tile) {
     return r;
 }
 
-int layout(mj_batch *b, MjPrep &pp, uint32_t flags, bool may_span) {
+int layout(mj_batch *b, MjPrep &pp, uint32_t flags, bool may_span, bool may_spec) {
     const std::vector<MjPrepared> &prep = pp.img;
     const int n = (int) prep.size();
     b->span_src = nullptr;
@@ -630,11 +653,50 @@ int layout(mj_batch *b, MjPrep &pp, uint32_t flags, bool may_span) {
     b->multi = pp.multi;
     b->comb.clear();
 
+    /* How the subsequences are synchronised.  The rounds are a chain, and in scans without
+     * restart markers a long one (some thirty serial decodes, and as many again across the
+     * sequences); a batch that leaves most of the chip idle waits for little else.  The
+     * speculative form (mj_spec_core.h) decodes every lane once per block slot and a little
+     * further -- fifteen to twenty-four times the work for 4:2:0 -- and has no chain.  It is
+     * taken where that work is what the chip does in a fraction of a millisecond and the chains
+     * are long: most of the batch in intervals of 256 kbit or more (files with a restart
+     * interval per MCU row synchronise in a few rounds as they are), lanes of one subsequence if
+     * the work allows and of two otherwise (longer lanes start too seldom: too many guesses). */
+    uint32_t spec_x = 0, spec_g = 0, spec_s = 0, spec_bpm = 1;
+    if (may_spec && !(flags & MJ_ENTROPY_SERIAL) && g_sync.mode != 1) {
+        uint64_t bits = 0, long_bits = 0;
+        for (int i = 0; i < n; i++) {
+            const MjImageDev &im = prep[i].im;
+            bits += im.raw_len * 8;
+            if (im.raw_len * 8 >= (uint64_t) MJ_SPEC_LONG_INTERVAL_BITS * im.n_ivl) long_bits += im.raw_len * 8;
+            spec_bpm = im.bpm > spec_bpm ? im.bpm : spec_bpm;
+        }
+        uint32_t cus = 0;
+        if (mj_device_cus(&cus) != hipSuccess) return set_err("cannot query the device");
+        const uint64_t limit = (uint64_t) MJ_SPEC_MAX_WORK_BITS_PER_CU * cus;
+        const bool chains = spec_bpm >= 2 && 2 * long_bits > bits;
+        for (uint32_t g = 1; g <= MJ_MAX_LANE_SUBS && !spec_x; g *= 2) {
+            if (g_sync.lane_subs ? g != g_sync.lane_subs : (g_sync.mode != 2 && g > 2)) continue;
+            const uint32_t x = mj_spec_fit_x(g, spec_bpm, g_sync.extra ? g_sync.extra : spec_default_extra(g));
+            if (x == 0) continue;
+            const uint64_t work = bits * spec_bpm * (g + x) / g;
+            if (g_sync.mode == 2 || (chains && work <= limit)) {
+                spec_x = x;
+                spec_g = g;
+            }
+        }
+        spec_s = g_sync.sub_bits ? (g_sync.sub_bits + 31u) / 32u * 32u : MJ_SPEC_SUB_BITS;
+    }
+
     uint64_t raw_total = 0, cmp_total = 0, coef_blocks = 0, rgb_total = 0, plane_total = 0;
     uint64_t n_tiles = 0, n_ivl = 0, n_seq = 0, n_rec = 0, n_wg = 0, n_multi = 0, n_idct = 0;
     for (int i = 0; i < n; i++) {
         MjImageDev &im = b->img[i];
         im = prep[i].im;
+        if (spec_x) {
+            im.sub_bits = spec_s;
+            im.lane_subs = spec_g;
+        }
         if (im.raw_len >= (1ull << 28)) {
             return set_err("image %d: entropy segment of %llu bytes is too large", i, (unsigned long long) im.raw_len);
         }
@@ -797,6 +859,9 @@ int layout(mj_batch *b, MjPrep &pp, uint32_t flags, bool may_span) {
 #else
     d.dbg = 0;
 #endif
+    d.spec = spec_x;
+    d.spec_bpm = spec_bpm;
+    d.spec_stride = spec_x ? spec_bpm * mj_spec_len(spec_g, spec_x) : 0;
     d.max_ntab = 1;
     d.max_nac = 1;
     for (const MjHuffSet &hs : b->sets) {
@@ -836,6 +901,10 @@ int layout(mj_batch *b, MjPrep &pp, uint32_t flags, bool may_span) {
     o.raw = w.take(b->raw_bytes);
     o.cmp = w.take(cmp_total + 64);
     o.rec = w.take(n_rec * sizeof(MjSubRec));
+    o.spec_rec = w.take(spec_x ? n_rec / spec_g * d.spec_stride * sizeof(MjSubRec) : 0);
+    o.spec_map = w.take(spec_x ? n_rec * MJ_SPEC_MAXC : 0);
+    o.spec_tot = w.take(spec_x ? n_seq * MJ_SPEC_MAXC : 0);
+    o.spec_brk = w.take(spec_x ? n_seq * 4 : 0);
     o.work_bytes = w.off;
     o.coefs = out.take(b->coef_bytes);
     o.rgb = out.take(rgb_total);
@@ -874,6 +943,10 @@ void bind(mj_batch *b, uint8_t *meta, uint8_t *state, uint8_t *work, uint8_t *co
     d.raw = work + o.raw;
     d.cmp = work + o.cmp;
     d.rec = reinterpret_cast<MjSubRec *>(work + o.rec);
+    d.spec_rec = reinterpret_cast<MjSubRec *>(work + o.spec_rec);
+    d.spec_map = work + o.spec_map;
+    d.spec_tot = work + o.spec_tot;
+    d.spec_brk = reinterpret_cast<uint32_t *>(work + o.spec_brk);
     d.coefs = reinterpret_cast<int16_t *>(coefs);
     d.rgb = rgb;
     d.planes = planes;
@@ -1002,7 +1075,7 @@ int enqueue_decode(mj_batch *b, hipStream_t s) {
         HIP_TRY(mark(3));
         HIP_TRY(mark(4));
     } else {
-        HIP_TRY(mj_launch_entropy(b->d, s));
+        HIP_TRY(b->d.spec ? mj_launch_spec(b->d, s) : mj_launch_entropy(b->d, s));
         HIP_TRY(mark(3));
         HIP_TRY(mj_launch_entropy_fix(b->d, s));
         HIP_TRY(mj_launch_entropy_write(b->d, s));
@@ -1061,7 +1134,7 @@ void batch_free(mj_batch *b, bool park) {
 int fill_own(mj_batch *b, MjPrep &pp, uint32_t flags, bool own_stage, bool wait) {
     mj_ctx *ctx = b->ctx;
     const std::vector<MjPrepared> &prep = pp.img;
-    if (layout(b, pp, flags, true)) return -1;
+    if (layout(b, pp, flags, true, true)) return -1;
     const Offsets &o = b->o;
     const size_t need = o.meta_bytes + o.state_bytes + o.work_bytes + o.out_bytes;
     if (arena_reserve(b, need)) return -1;
@@ -1190,6 +1263,20 @@ void mj_destroy(mj_ctx *ctx) {
     if (ctx->arena) (void) hipFree(ctx->arena);
     if (ctx->conv) (void) hipFree(ctx->conv);
     delete ctx;
+}
+
+int mj_set_sync_policy(int mode, int sub_bits, int lane_subs, int extra) {
+    if (mode < 0 || mode > 2) return set_err("mj_set_sync_policy: mode %d (0, 1 or 2)", mode);
+    if (sub_bits < 0 || sub_bits > 32768) return set_err("mj_set_sync_policy: sub_bits %d", sub_bits);
+    if (lane_subs != 0 && lane_subs != 1 && lane_subs != 2 && lane_subs != 4 && lane_subs != 8) {
+        return set_err("mj_set_sync_policy: lane_subs %d (0, 1, 2, 4 or 8)", lane_subs);
+    }
+    if (extra < 0 || extra > 8) return set_err("mj_set_sync_policy: extra %d (0 .. 8)", extra);
+    g_sync.mode = (uint32_t) mode;
+    g_sync.sub_bits = (uint32_t) sub_bits;
+    g_sync.lane_subs = (uint32_t) lane_subs;
+    g_sync.extra = (uint32_t) extra;
+    return 0;
 }
 
 int mj_device_pci_bus_id(int device, char *buf, size_t cap) {
@@ -1380,7 +1467,7 @@ int mj_decode_static(mj_ctx *ctx, const uint8_t *const *bufs, const size_t *lens
         return set_err("mj_decode_static: image %u is coded in several scans, which need plane memory this entry point has none of",
                        prep.multi.front().file);
     }
-    if (layout(b, prep, flags, true)) return -1;
+    if (layout(b, prep, flags, true, false)) return -1;      /* the work memory is fixed: no room for speculation */
     const Offsets &o = b->o;
     const size_t need = o.meta_bytes + o.state_bytes + o.work_bytes;
     if (need > (size_t) MJ_STATIC_SCRATCH_BYTES || o.meta_bytes > b->meta_cap) {

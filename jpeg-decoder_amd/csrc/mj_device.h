@@ -183,7 +183,8 @@ typedef struct {
     uint32_t n_rst;      /* restart markers found before the terminator */
     uint32_t n_seq;      /* sequences laid out */
     uint32_t status;     /* bit 0 stream overrun, bit 1 missing restart markers */
-    uint32_t pad_[3];
+    uint32_t spec_guessed; /* speculative synchronisation: hops of the image's true chains that were guesses */
+    uint32_t pad_[2];
 } MjImageDyn;
 
 /* What a decoder knows at a symbol boundary; equal states decode identically

@@ -13,6 +13,7 @@
 #include "../host/mj_host.h"
 #include "mj_colour_core.h"
 #include "mj_entropy_core.h"
+#include "mj_spec_core.h"
 
 namespace {
 
@@ -108,6 +109,61 @@ int mj_emu_wrap_sum_pairs(void) {
     return n;
 }
 
+/* mj_spec_core.h checked against a brute-force walk: for lanes of G subsequences with X more,
+ * every candidate that exists at a position and goes on is a candidate at the next position
+ * with the index mj_spec_next says, one subsequence older, and the candidates that exist are
+ * exactly the lanes whose trajectories cover the position.  Returns 0, or the line that failed. */
+int mj_emu_spec_selftest(void) {
+    for (uint32_t G = 1; G <= 8; G *= 2) {
+        for (uint32_t X = 1; X <= 6; X++) {
+            for (uint32_t bpm = 1; bpm <= 10; bpm++) {
+                const uint32_t x = mj_spec_fit_x(G, bpm, X);
+                if (x == 0) return __LINE__;
+                if ((mj_spec_back(G, x) + 1) * bpm > MJ_SPEC_MAXC || mj_spec_back(G, x) > MJ_SPEC_MAX_BACK) return __LINE__;
+                if (x != X) continue;
+                for (uint32_t m = 0; m < 5 * G + 7; m++) {
+                    const uint32_t l0 = m / G, a0 = m % G;
+                    for (uint32_t r = 0; r <= mj_spec_back(G, X) + 1; r++) {
+                        for (uint32_t v = 0; v < bpm; v++) {
+                            /* lane l0 - r starts at subsequence (l0 - r) * G and covers G + X of them */
+                            const bool covers = r <= l0 && m < (l0 - r) * G + G + X && (l0 != r || v == 0);
+                            if (covers != mj_spec_valid(G, X, l0, a0, r, v)) return __LINE__;
+                            if (!covers) continue;
+                            if (mj_spec_age(G, a0, r) != m - (l0 - r) * G) return __LINE__;
+                            const uint32_t nx = mj_spec_next(G, X, bpm, a0, r, v);
+                            const bool goes_on = m + 1 < (l0 - r) * G + G + X;
+                            if (goes_on != (nx != MJ_SPEC_END)) return __LINE__;
+                            if (goes_on) {
+                                const uint32_t l1 = (m + 1) / G, r1 = nx / bpm, v1 = nx % bpm;
+                                if (v1 != v || l1 - r1 != l0 - r) return __LINE__;
+                                if (!mj_spec_valid(G, X, l1, (m + 1) % G, r1, v1)) return __LINE__;
+                            }
+                        }
+                    }
+                    /* the guess is a candidate of the next position that goes on from this one */
+                    const uint32_t gs = mj_spec_guess(G, X, bpm, a0) & MJ_SPEC_IDX;
+                    if (!mj_spec_valid(G, X, (m + 1) / G, (m + 1) % G, gs / bpm, gs % bpm)) return __LINE__;
+                }
+            }
+        }
+    }
+    /* composition: the later map's flag survives, the earlier one's does not */
+    uint8_t a[MJ_SPEC_MAXC], b2[MJ_SPEC_MAXC], c[MJ_SPEC_MAXC];
+    for (uint32_t i = 0; i < MJ_SPEC_MAXC; i++) {
+        a[i] = (uint8_t) (((i * 7 + 3) % MJ_SPEC_MAXC) | ((i & 1) ? MJ_SPEC_UNVERIFIED : 0));
+        b2[i] = (uint8_t) (((i * 5 + 1) % MJ_SPEC_MAXC) | ((i % 3 == 0) ? MJ_SPEC_UNVERIFIED : 0));
+    }
+    mj_spec_compose(a, b2, c);
+    for (uint32_t i = 0; i < MJ_SPEC_MAXC; i++) {
+        if (c[i] != b2[a[i] & MJ_SPEC_IDX]) return __LINE__;
+    }
+    if (mj_spec_rank(mj_spec_state(100, 0x0305), mj_spec_state(100, 0x0305)) != 3) return __LINE__;
+    if (mj_spec_rank(mj_spec_state(100, 0x0305), mj_spec_state(100, 0x0309)) != 2) return __LINE__;
+    if (mj_spec_rank(mj_spec_state(100, 0x0305), mj_spec_state(101, 0x0305)) != 1) return __LINE__;
+    if (mj_spec_rank(mj_spec_state(100, 0x0305), mj_spec_state(100, 0x0405)) != 0) return __LINE__;
+    return 0;
+}
+
 /* the byte-at-a-time rule, for comparison */
 int mj_emu_classify(uint32_t prev, uint32_t cur, uint32_t next) {
     return mj_classify(prev, cur, next);
@@ -120,7 +176,12 @@ int mj_emu_classify(uint32_t prev, uint32_t cur, uint32_t next) {
  * sequences, [2] max rounds, [3] sequences, [4] multi-sequence intervals,
  * [5] fix-up iterations (max over intervals), [6] sub_bits used, [7] restart markers
  * found, [8] subsequences per lane, [9] subsequence decodes spent in the rounds.
- * force_sub_bits: low 16 bits = subsequence length, high 16 bits = subsequences per lane.
+ * [10] hops of the speculative synchronisation that were guesses, [11] subsequences the
+ * mending pass decoded, [12] the most it decoded from one guess.
+ * force_sub_bits: low 16 bits = subsequence length, bits 16-23 = subsequences per lane,
+ * bits 24-31 = X: when not 0 the records come from the speculative synchronisation
+ * (mj_spec_core.h: every lane once per block slot, X subsequences past its own) instead of
+ * the rounds.
  * Returns the number of blocks, or -1.
  */
 int64_t mj_emu_decode_coefs(const uint8_t *file, size_t len, int16_t *coefs, int64_t cap_blocks, uint32_t force_sub_bits,
@@ -147,8 +208,17 @@ int64_t mj_emu_decode_coefs(const uint8_t *file, size_t len, int16_t *coefs, int
     if (force_sub_bits & 0xFFFFu) {
         img.sub_bits = ((force_sub_bits & 0xFFFFu) + 31) / 32 * 32;
     }
-    if (force_sub_bits >> 16) {
-        img.lane_subs = force_sub_bits >> 16;
+    if ((force_sub_bits >> 16) & 0xFFu) {
+        img.lane_subs = (force_sub_bits >> 16) & 0xFFu;
+    }
+    uint32_t spec_x = force_sub_bits >> 24;
+    if (spec_x) {
+        spec_x = mj_spec_fit_x(img.lane_subs, img.bpm, spec_x);
+        if (spec_x == 0) {
+            mj_parsed_free(&P);
+            free(set);
+            return -1;
+        }
     }
     const uint32_t S = img.sub_bits, G = img.lane_subs, SQ = MJ_SEQ_LANES * G;
 
@@ -169,7 +239,7 @@ int64_t mj_emu_decode_coefs(const uint8_t *file, size_t len, int16_t *coefs, int
     wcx.pairs = (const unsigned char *) set->next;
     wcx.pair_stride = (uint32_t) sizeof(MjHuffPair);
 
-    int64_t st_subs = 0, st_rounds = 0, st_maxr = 0, st_seqs = 0, st_multi = 0, st_fix = 0, st_tasks = 0;
+    int64_t st_subs = 0, st_rounds = 0, st_maxr = 0, st_seqs = 0, st_multi = 0, st_fix = 0, st_tasks = 0, st_guess = 0, st_mend = 0, st_mendmax = 0;
     // MJ_EMU_HIST=1: print, per round, how many decoders are still out of step and by which part of the state
     int64_t hist_store[64] = {0};
     int64_t *hist = getenv("MJ_EMU_HIST") ? hist_store : nullptr;
@@ -191,8 +261,59 @@ int64_t mj_emu_decode_coefs(const uint8_t *file, size_t len, int16_t *coefs, int
         auto sub_end = [&](uint32_t j) { return (j + 1 == nsub) ? b1 : b0 + (j + 1) * S; };
         std::vector<Rec> rec(nsub);
 
+        if (spec_x) {
+            // ---- speculative synchronisation: every lane in every variant, G + X subsequences each ----
+            const uint32_t X = spec_x, bpm = img.bpm, len_t = mj_spec_len(G, X);
+            const uint32_t nlanes = (nsub + G - 1) / G;
+            std::vector<Rec> node((size_t) nlanes * bpm * len_t, Rec{0xFFFFFFFFu, 0, 0, 0, {0, 0, 0, 0}});
+            for (uint32_t l = 0; l < nlanes; l++) {
+                for (uint32_t v = 0; v < (l ? bpm : 1u); v++) {
+                    Rec cur{b0 + l * G * S, 0, v, 0, {0, 0, 0, 0}};
+                    for (uint32_t a = 0; a < len_t && l * G + a < nsub; a++) {
+                        cur = span(cx, cur.p, cur.k, cur.c, sub_end(l * G + a));
+                        node[((size_t) l * bpm + v) * len_t + a] = cur;
+                    }
+                }
+            }
+            auto node_at = [&](uint32_t m, uint32_t r, uint32_t v) -> const Rec & {
+                return node[((size_t) (m / G - r) * bpm + v) * len_t + mj_spec_age(G, m % G, r)];
+            };
+            // the chain: candidate 0 at position 0, then the maps (the kernels compose them as a scan)
+            std::vector<char> guessed(nsub, 0);
+            uint32_t at = 0;
+            for (uint32_t m = 0; m < nsub; m++) {
+                const uint32_t r = (at & MJ_SPEC_IDX) / bpm, v = (at & MJ_SPEC_IDX) % bpm;
+                rec[m] = node_at(m, r, v);
+                guessed[m] = (at & MJ_SPEC_UNVERIFIED) != 0;
+                st_guess += guessed[m];
+                if (m + 1 < nsub) {
+                    uint8_t g[MJ_SPEC_MAXC];
+                    mj_spec_map(G, X, bpm, m / G, m % G, [&](uint32_t r2, uint32_t v2) {
+                        const Rec &n = node_at(m, r2, v2);
+                        return mj_spec_state(n.p, (n.c << 8) | n.k);
+                    }, g);
+                    at = g[at & MJ_SPEC_IDX];
+                }
+            }
+            // mending: from the last verified state on until the records are met again
+            for (uint32_t m = 1; m < nsub; m++) {
+                if (!guessed[m]) continue;
+                Rec cur = rec[m - 1];
+                int64_t steps = 0;
+                for (uint32_t l = m; l < nsub; l++) {
+                    steps++;
+                    if (steps > st_mendmax) st_mendmax = steps;
+                    const Rec o = span(cx, cur.p, cur.k, cur.c, sub_end(l));
+                    const bool synced = same_state(o, rec[l]);
+                    rec[l] = o;
+                    cur = o;
+                    st_mend++;
+                    if (synced) break;
+                }
+            }
+        }
         // ---- kernel A: per sequence, one lane per G consecutive subsequences ------
-        for (uint32_t q = 0; q < nseq; q++) {
+        for (uint32_t q = 0; q < nseq && !spec_x; q++) {
             const uint32_t first = q * SQ;
             const uint32_t n = (nsub - first < SQ) ? nsub - first : SQ;
             std::vector<Task> tasks;
@@ -236,7 +357,7 @@ int64_t mj_emu_decode_coefs(const uint8_t *file, size_t len, int16_t *coefs, int
         }
 
         // ---- kernel B: cross-sequence fix-up (intervals longer than one sequence) --
-        if (nseq > 1) {
+        if (nseq > 1 && !spec_x) {
             st_multi++;
             std::vector<Rec> seen(nseq);
             std::vector<char> have(nseq, 0);
@@ -326,6 +447,9 @@ int64_t mj_emu_decode_coefs(const uint8_t *file, size_t len, int16_t *coefs, int
         stats[7] = L.n_rst;
         stats[8] = G;
         stats[9] = st_tasks;
+        stats[10] = st_guess;
+        stats[11] = st_mend;
+        stats[12] = st_mendmax;
     }
     mj_parsed_free(&P);
     free(set);

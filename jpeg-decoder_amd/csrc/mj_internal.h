@@ -66,6 +66,14 @@ struct MjDeviceBatch {
     uint2 *pair_list;        /* [n_sync_pairs at most] (image, first group) of every two groups of one image (its last may be a single one) */
     uint32_t n_sync_pairs;   /* upper bound, like n_entropy_wg */
     uint32_t n_busy_groups;  /* lower bound on the workgroups that will hold work: per image the larger of its restart intervals and its bytes over a sequence's, in eights */
+    /* speculative synchronisation (mj_spec_core.h), for batches that leave the chip idle: every image has the same lane_subs then */
+    uint32_t spec;           /* 0: the rounds of mj_k_entropy_sync; else X, the subsequences a lane decodes past its own */
+    uint32_t spec_stride;    /* records per lane slot in spec_rec: most block slots per MCU in the batch x (lane_subs + X) */
+    uint32_t spec_bpm;       /* most block slots per MCU in the batch */
+    MjSubRec *spec_rec;      /* per lane slot (rec_off / lane_subs + 64 x sequence + lane), variant and subsequence of the trajectory */
+    uint8_t *spec_map;       /* per record slot: MJ_SPEC_MAXC bytes, candidate at the sequence's first position -> candidate here */
+    uint8_t *spec_tot;       /* per sequence slot: MJ_SPEC_MAXC bytes, what the whole sequence does to a candidate */
+    uint32_t *spec_brk;      /* per sequence slot: hops of the true chain in it that were guesses */
     const MjIdctImg *idct_img; /* [n_img] what the IDCT + colour kernel reads per image */
     const MjCombine *comb;   /* [n_comb] frames coded in one scan per component */
     uint32_t n_comb, comb_max_x, comb_max_y;
@@ -87,6 +95,7 @@ struct MjDeviceBatch {
 /* Stage launchers; all asynchronous on `s`.  Return hipSuccess or the launch error. */
 hipError_t mj_launch_scan(const MjDeviceBatch &b, hipStream_t s);
 hipError_t mj_launch_entropy(const MjDeviceBatch &b, hipStream_t s);
+hipError_t mj_launch_spec(const MjDeviceBatch &b, hipStream_t s);
 hipError_t mj_launch_entropy_fix(const MjDeviceBatch &b, hipStream_t s);
 hipError_t mj_launch_entropy_write(const MjDeviceBatch &b, hipStream_t s);
 hipError_t mj_launch_entropy_serial(const MjDeviceBatch &b, hipStream_t s);

@@ -44,6 +44,7 @@
 
 #include "mj_entropy_core.h"
 #include "mj_internal.h"
+#include "mj_spec_core.h"
 
 namespace {
 
@@ -666,7 +667,10 @@ __global__ __launch_bounds__(MJ_WG_SEQS * 64) void mj_k_entropy_fix_first(MjDevi
         const MjState e = rec[-1].exit;
         if (lane == 0) b.seq_seen[im.seq_off + sq] = e;
         uint32_t p = uni(e.p), kc = uni(e.kc);
-        for (uint32_t l = 0; l < n; l++) {
+        /* records that come from the speculative synchronisation without a single guess in the
+         * image are one verified chain across all its sequences: nothing to decode again */
+        const uint32_t n_redo = (b.spec && b.dyn[ii].spec_guessed == 0) ? 0u : n;
+        for (uint32_t l = 0; l < n_redo; l++) {
             const MjState old = rec[l].exit;
             const LaneRec o = solo_nowrite(cx, p, kc, sub_end(g.b0, g.b1, g.nsub, first + l, S), lane);
             if (lane == 0) store_rec(rec + l, o);
@@ -954,6 +958,368 @@ __global__ __launch_bounds__(TPB) void mj_k_entropy_write(MjDeviceBatch b) {
 }
 
 /* ------------------------------------------------------------------------ */
+/* speculative synchronisation: the records without the rounds              */
+/* ------------------------------------------------------------------------ */
+/* For batches that leave most of the chip idle (a file or a few dozen small ones), where the
+ * rounds of mj_k_entropy_sync are a chain of some tens of serial decodes that nothing runs
+ * beside.  mj_spec_core.h has the idea; here:
+ *   mj_k_spec_decode   every lane once per block slot ("variant"), its own G subsequences and
+ *                      X more, a record after each (grid: groups of sequences x variants);
+ *   mj_k_spec_maps     per subsequence end the map "candidate here -> candidate at the next
+ *                      end", composed into prefix maps from the start of the sequence and one
+ *                      total map per sequence (a scan inside every wavefront);
+ *   mj_k_spec_resolve  the candidate the true decode is at when it enters the sequence (the
+ *                      totals of the sequences before it, folded), then through the prefix
+ *                      maps the true candidate at every subsequence end, whose record is
+ *                      copied to where the other kernels expect the records;
+ *   mj_k_spec_mend     where the chain had to guess (nothing that goes on stood where the true
+ *                      decode stood when its trajectory ended): decode on from the last
+ *                      verified state until the records agree, as a round would.
+ * The cross-sequence kernels then run as for any batch: every sequence boundary is decoded
+ * across once more, and whatever the mending left open across boundaries is settled there. */
+constexpr int SPEC_TPB = MJ_WG_SEQS * 64;
+
+struct SpecSeq {          /* what a wavefront knows about its sequence */
+    Geo g;
+    uint32_t first, n;    /* first subsequence within the interval, subsequences in the sequence */
+    uint32_t rec_base;    /* record slot of its first subsequence */
+    uint32_t lane_base;   /* lane slot (batch-wide) of the interval's first lane */
+    uint32_t seq_slot;    /* sequence slot (batch-wide) */
+};
+
+__device__ __forceinline__ SpecSeq spec_seq(const MjDeviceBatch &b, const MjImageDev &im, uint32_t seq) {
+    SpecSeq s;
+    const uint32_t G = im.lane_subs, SQ = MJ_SEQ_LANES * G;
+    const uint32_t iv = b.seq_ivl[im.seq_off + seq];
+    s.g = interval_geo(b.ivl_start + im.ivl_off, iv, im.sub_bits, SQ);
+    s.first = b.seq_sub[im.seq_off + seq];
+    s.n = min(s.g.nsub - s.first, SQ);
+    s.rec_base = im.rec_off + seq * SQ;
+    s.lane_base = im.rec_off / G + b.ivl_seq[im.ivl_off + iv] * MJ_SEQ_LANES;
+    s.seq_slot = im.seq_off + seq;
+    return s;
+}
+
+/* the records of the trajectory of lane `lane` (of the interval) in variant v */
+__device__ __forceinline__ MjSubRec *spec_nodes(const MjDeviceBatch &b, const SpecSeq &s, uint32_t lane, uint32_t v, uint32_t len) {
+    return b.spec_rec + ((uint64_t) (s.lane_base + lane) * b.spec_stride + v * len);
+}
+
+/* LDS written by some lanes of a wavefront and read by others of the same wavefront */
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+/* The sequences of a block: a group of MJ_WG_SEQS sequences is taken by one block of as many
+ * wavefronts or by several smaller ones (a batch of a few sequences is done sooner with its
+ * wavefronts spread over many compute units than with eight to a unit).  seq0: the first
+ * sequence (of the image) of the block; false when there is none. */
+__device__ __forceinline__ bool spec_my_seq(const MjDeviceBatch &b, uint32_t &ii, uint32_t &seq0, uint32_t &n_seq) {
+    const uint32_t wpb = blockDim.x >> 6, parts = MJ_WG_SEQS / wpb;
+    const uint32_t grp = blockIdx.x / parts, part = blockIdx.x % parts;
+    if (grp >= b.multi_count[2]) return false;
+    const uint2 ge = b.grp_list[grp];
+    ii = ge.x;
+    n_seq = b.dyn[ii].n_seq;
+    seq0 = ge.y * MJ_WG_SEQS + part * wpb;
+    return seq0 < n_seq;
+}
+
+__global__ __launch_bounds__(SPEC_TPB) void mj_k_spec_decode(MjDeviceBatch b) {
+    uint32_t ii, seq0, n_seq;
+    if (!spec_my_seq(b, ii, seq0, n_seq)) return;
+    const MjImageDev &im = b.img[ii];
+    const uint32_t v = blockIdx.y;
+    if (v >= im.bpm) return;
+    unsigned char *s_pairs = lds_after_dc(b, 0);
+    load_tables(b, im, s_pairs, true);
+    __syncthreads();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (seq0 + wave >= n_seq) return;
+    const SpecSeq s = spec_seq(b, im, seq0 + wave);
+    const uint32_t S = im.sub_bits, G = im.lane_subs, LEN = mj_spec_len(G, b.spec);
+    const uint32_t u0 = lane * G;
+    if (u0 >= s.n) return;
+    const uint32_t j0 = s.first + u0;
+    if (j0 == 0 && v != 0) return;            /* the first lane of an interval knows its slot */
+    const MjScanCtx cx = make_ctx(b, im, s_pairs, true);
+    MjLane L;
+    mj_lane_init(cx, L, s.g.b0 + j0 * S, 0, v);
+    MjSubRec *dst = spec_nodes(b, s, lane + (s.first / G), v, LEN);
+    for (uint32_t a = 0; a < LEN; a++) {
+        if (j0 + a < s.g.nsub) {
+            const LaneRec r = run_nowrite(cx, L, sub_end(s.g.b0, s.g.b1, s.g.nsub, j0 + a, S));
+            store_rec(dst + a, r);
+        }
+    }
+}
+
+/* out = second after first; maps are MJ_SPEC_MAXC bytes in LDS, read and written a word at a time */
+__device__ __forceinline__ void spec_compose(const uint8_t *first, const uint8_t *second, uint8_t *out) {
+    const uint32_t *f = reinterpret_cast<const uint32_t *>(first);
+    uint32_t *o = reinterpret_cast<uint32_t *>(out);
+#pragma unroll
+    for (int w = 0; w < MJ_SPEC_MAXC / 4; w++) {
+        const uint32_t x = f[w];
+        o[w] = (uint32_t) second[x & MJ_SPEC_IDX] | ((uint32_t) second[(x >> 8) & MJ_SPEC_IDX] << 8) |
+               ((uint32_t) second[(x >> 16) & MJ_SPEC_IDX] << 16) | ((uint32_t) second[(x >> 24) & MJ_SPEC_IDX] << 24);
+    }
+}
+__device__ __forceinline__ void spec_identity(uint8_t *m) {
+    uint32_t *o = reinterpret_cast<uint32_t *>(m);
+#pragma unroll
+    for (int w = 0; w < MJ_SPEC_MAXC / 4; w++) o[w] = 0x03020100u + 0x04040404u * (uint32_t) w;
+}
+__device__ __forceinline__ void spec_copy(const uint8_t *src, uint8_t *dst) {       /* both 16-byte aligned */
+    const uint4 *a = reinterpret_cast<const uint4 *>(src);
+    uint4 *d = reinterpret_cast<uint4 *>(dst);
+    d[0] = a[0];
+    d[1] = a[1];
+}
+
+__global__ __launch_bounds__(SPEC_TPB) void mj_k_spec_maps(MjDeviceBatch b) {
+    /* dynamic LDS: three maps per thread */
+    uint32_t ii, seq0, n_seq;
+    if (!spec_my_seq(b, ii, seq0, n_seq)) return;
+    const MjImageDev &im = b.img[ii];
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (seq0 + wave >= n_seq) return;         /* no workgroup barrier below: every wavefront works alone */
+    const SpecSeq s = spec_seq(b, im, seq0 + wave);
+    const uint32_t G = im.lane_subs, X = b.spec, LEN = mj_spec_len(G, X), bpm = im.bpm;
+    uint8_t *maps = b.spec_map + (uint64_t) s.rec_base * MJ_SPEC_MAXC;
+    auto M = [&](uint32_t k, uint32_t l) -> uint8_t * { return s_dyn + (size_t) (k * blockDim.x + (wave << 6) + l) * MJ_SPEC_MAXC; };
+
+    const uint32_t lg = 31u - (uint32_t) __clz((int) G);       /* lane_subs is a power of two */
+    const uint32_t back = mj_spec_back(G, X);
+    /* the maps of the lane's positions as far as indices decide them (a position has a map when
+     * a subsequence follows it in its interval), put together in LDS */
+    for (uint32_t q = 0; q < G; q++) {
+        const uint32_t u = lane * G + q, m = s.first + u;
+        if (u < s.n && m + 1 < s.g.nsub) {
+            const uint32_t l0 = m >> lg, a0 = m & (G - 1u);
+            uint8_t *t = M(1, lane);
+            const uint32_t guess = mj_spec_guess(G, X, bpm, a0) * 0x01010101u;
+#pragma unroll
+            for (int w = 0; w < MJ_SPEC_MAXC / 4; w++) reinterpret_cast<uint32_t *>(t)[w] = guess;
+            for (uint32_t r = 0; r <= back; r++) {
+                for (uint32_t v = 0; v < bpm; v++) t[r * bpm + v] = mj_spec_entry(G, X, bpm, l0, a0, r, v);
+            }
+            spec_copy(t, maps + (uint64_t) u * MJ_SPEC_MAXC);
+        }
+    }
+    __threadfence_block();
+    /* The trajectories that end inside the sequence, one per lane and variant: lane t looks at the
+     * t-th position where one ends (positions LEN - 1, LEN - 1 + G, ... of the interval).  The
+     * candidates that go on there are those of the lanes after the one that ends: their states
+     * first, all loads at once, then every variant that ends against all of them. */
+    {
+        const uint32_t u = ((LEN - 1u) & (G - 1u)) + lane * G, m = s.first + u;
+        if (u < s.n && m + 1 < s.g.nsub && m >= LEN - 1u) {
+            const uint32_t l0 = m >> lg, a0 = m & (G - 1u);
+            const uint32_t r = (LEN - 1u - a0) >> lg;
+            uint64_t theirs[MJ_SPEC_MAX_BACK][MJ_MAX_BPM];
+            uint32_t their_next[MJ_SPEC_MAX_BACK][MJ_MAX_BPM];
+#pragma unroll
+            for (uint32_t r2 = 0; r2 < MJ_SPEC_MAX_BACK; r2++) {
+#pragma unroll
+                for (uint32_t v2 = 0; v2 < MJ_MAX_BPM; v2++) {
+                    const bool on = r2 < r && v2 < bpm && mj_spec_valid(G, X, l0, a0, r2, v2);
+                    their_next[r2][v2] = on ? mj_spec_next(G, X, bpm, a0, r2, v2) : (uint32_t) MJ_SPEC_END;
+                    theirs[r2][v2] = 0;
+                    if (on) {
+                        const MjState st = spec_nodes(b, s, l0 - r2, v2, LEN)[mj_spec_age(G, a0, r2)].exit;
+                        theirs[r2][v2] = mj_spec_state(st.p, st.kc);
+                    }
+                }
+            }
+            for (uint32_t v = 0; v < bpm; v++) {
+                if (!mj_spec_valid(G, X, l0, a0, r, v)) continue;
+                const MjState st = spec_nodes(b, s, l0 - r, v, LEN)[LEN - 1u].exit;
+                const uint64_t mine = mj_spec_state(st.p, st.kc);
+                uint32_t rank = 0;
+                uint8_t e = mj_spec_guess(G, X, bpm, a0);
+#pragma unroll
+                for (uint32_t r2 = 0; r2 < MJ_SPEC_MAX_BACK; r2++) {
+#pragma unroll
+                    for (uint32_t v2 = 0; v2 < MJ_MAX_BPM; v2++) {
+                        if (their_next[r2][v2] != MJ_SPEC_END) mj_spec_better(mine, theirs[r2][v2], their_next[r2][v2], &rank, &e);
+                    }
+                }
+                maps[(uint64_t) u * MJ_SPEC_MAXC + r * bpm + v] = e;
+            }
+        }
+    }
+    __threadfence_block();
+
+    /* the lane's own positions composed: what its G subsequences do to a candidate.  All lanes
+     * do the same steps (a position without a map counts as the identity), so the running map
+     * is in the same buffer in every lane: 0 and 2 in turn, 1 holds the map being applied. */
+    uint32_t a = 0;
+    spec_identity(M(a, lane));
+    for (uint32_t q = 0; q < G; q++) {
+        const uint32_t u = lane * G + q, m = s.first + u;
+        if (u < s.n && m + 1 < s.g.nsub) {
+            spec_copy(maps + (uint64_t) u * MJ_SPEC_MAXC, M(1, lane));
+        } else {
+            spec_identity(M(1, lane));
+        }
+        spec_compose(M(a, lane), M(1, lane), M(2 - a, lane));
+        a = 2 - a;
+    }
+    /* inclusive scan over the lanes: after the step with distance d lane l holds what the lanes
+     * l - 2d + 1 .. l do, the earlier ones first */
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        wave_lds_sync();
+        if (lane >= d) {
+            spec_compose(M(a, lane - d), M(a, lane), M(2 - a, lane));
+        } else {
+            spec_copy(M(a, lane), M(2 - a, lane));
+        }
+        a = 2 - a;
+    }
+    wave_lds_sync();
+    /* what the whole sequence does (the lanes past its end count as the identity) */
+    if (lane == 63) spec_copy(M(a, 63), b.spec_tot + (uint64_t) s.seq_slot * MJ_SPEC_MAXC);
+    /* exclusive: what the lanes before this one do */
+    if (lane) {
+        spec_copy(M(a, lane - 1), M(1, lane));
+    } else {
+        spec_identity(M(1, lane));
+    }
+    wave_lds_sync();
+    /* the prefix map of every position -- candidate at the sequence's first position -> candidate
+     * here -- in place of its own map */
+    uint32_t run = 1, base = a, out = 2 - a;
+    for (uint32_t q = 0; q < G; q++) {
+        const uint32_t u = lane * G + q, m = s.first + u;
+        if (u >= s.n) break;
+        if (m + 1 < s.g.nsub) {
+            spec_copy(maps + (uint64_t) u * MJ_SPEC_MAXC, M(base, lane));
+        } else {
+            spec_identity(M(base, lane));
+        }
+        spec_compose(M(run, lane), M(base, lane), M(out, lane));
+        spec_copy(M(run, lane), maps + (uint64_t) u * MJ_SPEC_MAXC);
+        const uint32_t t = run;
+        run = out;
+        out = t;
+    }
+}
+
+__global__ __launch_bounds__(SPEC_TPB) void mj_k_spec_resolve(MjDeviceBatch b) {
+    uint8_t (*s_fold)[MJ_SPEC_MAXC] = reinterpret_cast<uint8_t (*)[MJ_SPEC_MAXC]>(s_dyn);      /* dynamic LDS: a map per thread */
+    uint32_t ii, seq0, n_seq;
+    if (!spec_my_seq(b, ii, seq0, n_seq)) return;
+    const MjImageDev &im = b.img[ii];
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (seq0 + wave >= n_seq) return;
+    const SpecSeq s = spec_seq(b, im, seq0 + wave);
+    const uint32_t G = im.lane_subs, X = b.spec, LEN = mj_spec_len(G, X), bpm = im.bpm, SQ = MJ_SEQ_LANES * G;
+    (void) X;
+    const uint32_t lg = 31u - (uint32_t) __clz((int) G);       /* lane_subs is a power of two */
+    /* The candidate the true decode is at where it enters the sequence: candidate 0 at the
+     * interval's first position, taken through the total maps of the sequences before this one,
+     * 64 of them at a time (a tree of compositions inside the wavefront). */
+    uint32_t c = 0;
+    const uint32_t before = s.first / SQ;
+    const uint8_t *tot = b.spec_tot + (uint64_t) (s.seq_slot - before) * MJ_SPEC_MAXC;
+    uint8_t *mine = s_fold[threadIdx.x];
+    for (uint32_t q0 = 0; q0 < before; q0 += 64) {
+        wave_lds_sync();
+        if (q0 + lane < before) {
+            spec_copy(tot + (uint64_t) (q0 + lane) * MJ_SPEC_MAXC, mine);
+        } else {
+            spec_identity(mine);
+        }
+        for (uint32_t d = 1; d < 64; d <<= 1) {
+            wave_lds_sync();
+            if ((lane & (2 * d - 1)) == 0) spec_compose(mine, s_fold[threadIdx.x + d], mine);
+        }
+        wave_lds_sync();
+        c = s_fold[wave << 6][c & MJ_SPEC_IDX];
+    }
+    /* the true candidate at each of the lane's positions, and its record */
+    const uint8_t *maps = b.spec_map + (uint64_t) s.rec_base * MJ_SPEC_MAXC;
+    uint32_t guessed = 0;
+    for (uint32_t q = 0; q < G; q++) {
+        const uint32_t u = lane * G + q, m = s.first + u;
+        if (u >= s.n) break;
+        const uint32_t e = u ? maps[(uint64_t) u * MJ_SPEC_MAXC + (c & MJ_SPEC_IDX)] : c;
+        const uint32_t idx = e & MJ_SPEC_IDX, r = idx / bpm, v = idx % bpm;
+        MjSubRec rec = spec_nodes(b, s, (m >> lg) - r, v, LEN)[mj_spec_age(G, m & (G - 1u), r)];
+        rec.pad_ = (e & MJ_SPEC_UNVERIFIED) ? 1u : 0u;
+        guessed += rec.pad_;
+        b.rec[s.rec_base + u] = rec;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) guessed += __shfl_xor(guessed, d, 64);
+    if (lane == 0) {
+        b.spec_brk[s.seq_slot] = guessed;
+        if (guessed) {
+            atomicAdd(&b.stats[MJ_ST_ROUNDS], (unsigned long long) guessed);
+            atomicAdd(&b.dyn[ii].spec_guessed, guessed);
+        }
+    }
+}
+
+/* Where the chain guessed: the decoder that stands at the last verified state goes on, replacing
+ * the records, until it meets a record it agrees with that is not itself followed by a guess.
+ * One wavefront per sequence, its guesses in ascending order, one decoder at a time
+ * (solo_nowrite); a decoder stops at the end of its sequence, where the cross-sequence kernels
+ * take over. */
+__global__ __launch_bounds__(SPEC_TPB) void mj_k_spec_mend(MjDeviceBatch b) {
+    uint32_t ii, seq0, n_seq;
+    if (!spec_my_seq(b, ii, seq0, n_seq)) return;
+    const MjImageDev &im = b.img[ii];
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    /* lane t of every wavefront looks at sequence t of the block, so all decide alike whether to stay */
+    const bool some = lane < (blockDim.x >> 6) && seq0 + lane < n_seq && b.spec_brk[im.seq_off + seq0 + lane] != 0;
+    if (!__any(some)) return;
+    unsigned char *s_pairs = lds_after_dc(b, 0);
+    load_tables(b, im, s_pairs, true);
+    __syncthreads();
+    if (seq0 + wave >= n_seq) return;
+    const SpecSeq s = spec_seq(b, im, seq0 + wave);
+    if (b.spec_brk[s.seq_slot] == 0) return;
+    const MjScanCtx cx = make_ctx(b, im, s_pairs, true);
+    const uint32_t S = im.sub_bits, G = im.lane_subs;
+    MjSubRec *rec = b.rec + s.rec_base;
+    uint32_t cursor = 0, decoded = 0;
+    for (;;) {
+        uint32_t mine = 0xFFFFFFFFu;
+        for (uint32_t q = 0; q < G; q++) {
+            const uint32_t u = lane * G + q;
+            if (u >= cursor && u < s.n && mine == 0xFFFFFFFFu && rec[u].pad_ != 0) mine = u;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) mine = min(mine, (uint32_t) __shfl_xor(mine, d, 64));
+        const uint32_t u0 = uni(mine);
+        if (u0 == 0xFFFFFFFFu) break;
+        if (s.first + u0 == 0) {                /* cannot be: the first record of an interval is exact */
+            cursor = 1;
+            continue;
+        }
+        const MjState e = rec[(int64_t) u0 - 1].exit;     /* u0 == 0: the last record of the sequence before, same interval */
+        uint32_t p = uni(e.p), kc = uni(e.kc), l = u0;
+        for (; l < s.n; l++) {
+            const MjState old = rec[l].exit;
+            const uint32_t next_guessed = (l + 1 < s.n) ? rec[l + 1].pad_ : 0u;
+            const LaneRec o = solo_nowrite(cx, p, kc, sub_end(s.g.b0, s.g.b1, s.g.nsub, s.first + l, S), lane);
+            if (lane == 0) store_rec(rec + l, o);
+            decoded++;
+            p = o.p;
+            kc = o.kc;
+            if (uni(old.p) == o.p && uni(old.kc) == o.kc && uni(next_guessed) == 0) break;
+        }
+        __threadfence_block();                  /* lane 0's records, before the other lanes look at the flags again */
+        cursor = l + 1;
+    }
+    if (lane == 0 && decoded) atomicAdd(&b.stats[MJ_ST_TASKS], (unsigned long long) decoded);
+}
+
+/* ------------------------------------------------------------------------ */
 /* diagnostic: one lane per restart interval, no subsequence machinery      */
 /* ------------------------------------------------------------------------ */
 __global__ __launch_bounds__(TPB) void mj_k_entropy_serial(MjDeviceBatch b) {
@@ -1025,6 +1391,23 @@ hipError_t mj_launch_entropy(const MjDeviceBatch &b, hipStream_t s) {
     } else {
         hipLaunchKernelGGL(mj_k_entropy_sync<1>, dim3(b.n_entropy_wg), dim3(tpb), lds, s, b);
     }
+    return hipGetLastError();
+}
+
+hipError_t mj_launch_spec(const MjDeviceBatch &b, hipStream_t s) {
+    if (b.n_entropy_wg == 0) return hipSuccess;
+    uint32_t cus = 0;
+    const hipError_t e = mj_device_cus(&cus);
+    if (e != hipSuccess) return e;
+    /* few sequences: small blocks, so that they spread over the chip (the decode keeps two
+     * wavefronts to a block, which share the tables in LDS) */
+    const bool few = (uint64_t) b.n_entropy_wg * MJ_WG_SEQS <= 4ull * cus;
+    const uint32_t wd = few ? 2u : (uint32_t) MJ_WG_SEQS, wo = few ? 1u : (uint32_t) MJ_WG_SEQS;
+    const size_t lds = table_lds(b, 0) + (size_t) b.max_nac * sizeof(MjHuffRun);
+    hipLaunchKernelGGL(mj_k_spec_decode, dim3(b.n_entropy_wg * (MJ_WG_SEQS / wd), b.spec_bpm), dim3(wd * 64), lds, s, b);
+    hipLaunchKernelGGL(mj_k_spec_maps, dim3(b.n_entropy_wg * (MJ_WG_SEQS / wo)), dim3(wo * 64), (size_t) 3 * wo * 64 * MJ_SPEC_MAXC, s, b);
+    hipLaunchKernelGGL(mj_k_spec_resolve, dim3(b.n_entropy_wg * (MJ_WG_SEQS / wo)), dim3(wo * 64), (size_t) wo * 64 * MJ_SPEC_MAXC, s, b);
+    hipLaunchKernelGGL(mj_k_spec_mend, dim3(b.n_entropy_wg * (MJ_WG_SEQS / wo)), dim3(wo * 64), lds, s, b);
     return hipGetLastError();
 }
 

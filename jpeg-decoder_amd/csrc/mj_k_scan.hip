@@ -176,7 +176,8 @@ __global__ __launch_bounds__(TPB) void mj_k_scan_prefix(MjDeviceBatch b) {
         d.n_rst = carry_r;
         d.n_seq = 0;
         d.status = 0;
-        d.pad_[0] = d.pad_[1] = d.pad_[2] = 0;
+        d.spec_guessed = 0;
+        d.pad_[0] = d.pad_[1] = 0;
         b.dyn[ii] = d;
     }
 }

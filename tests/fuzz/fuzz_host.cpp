@@ -145,7 +145,11 @@ int main(int argc, char **argv) {
                 case 6: for (int k = 0; k < 3; k++) d[hdr + rnd() % (ent - 2)] = 0xFF; break;    // stray markers / stuffing
                 default: { size_t p = hdr + rnd() % (ent - 4); d[p] = 0xFF; d[p + 1] = (uint8_t) (0xD0 + rnd() % 8); break; }
             }
-            const uint32_t force = (v % 3 == 0) ? 0u : (v % 3 == 1) ? (128u | (1u << 16)) : (256u | (2u << 16));
+            // the library's own cut, two forced ones, and two forms of the speculative synchronisation
+            // (bits 24-31: subsequences a lane decodes past its own)
+            static const uint32_t forces[5] = {0u, 128u | (1u << 16), 256u | (2u << 16), 64u | (1u << 16) | (1u << 24),
+                                               256u | (2u << 16) | (3u << 24)};
+            const uint32_t force = forces[v % 5];
             const long long n = run_exact(d, out.data(), 20000, force, st);
             runs++;
             if (n < 0) rejected++;

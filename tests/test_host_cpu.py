@@ -72,6 +72,41 @@ def test_entropy_algorithm_emulated(name, sub_bits, lane_subs):
         assert st["lane_subs"] == lane_subs
 
 
+@pytest.mark.parametrize("name", ALL_FIXTURES + FATAL_FIXTURES)
+@pytest.mark.parametrize("sub_bits,lane_subs,extra", [(256, 1, 3), (256, 2, 3), (32, 1, 1), (64, 2, 1), (96, 4, 2), (128, 8, 4), (512, 1, 2)])
+def test_speculative_synchronisation_emulated(name, sub_bits, lane_subs, extra):
+    """The records looked up instead of decoded (every lane once per block slot, the chain of
+    candidates through the maps, mending where it had to guess): the same coefficient blocks as
+    the reference's, whatever the lanes are; short lanes with one extra subsequence make the
+    chain guess all the time."""
+    emu = J.Emu()
+    data, gold = load_fixture(name)
+    nref = gold["coefs"].shape[0]
+    got, st = emu.decode_coefs(data, nref + 16, sub_bits, lane_subs, extra)
+    assert np.array_equal(got[:nref], gold["coefs"])
+    assert st["rounds_sum"] == 0 and st["fix_iterations"] == 0       # no rounds were run
+    assert st["spec_mended"] >= st["spec_guesses"]
+
+
+def test_speculative_synchronisation_guesses_and_mends():
+    """On the 512 x 512 file: three extra subsequences per lane of one never guess; one extra
+    subsequence of 64 bits guesses often, and the mending decodes from every guess."""
+    emu = J.Emu()
+    data, gold = load_fixture("C1_c420_q85_512x512")
+    got, st = emu.decode_coefs(data, gold["coefs"].shape[0], 256, 1, 3)
+    assert np.array_equal(got, gold["coefs"]) and st["spec_guesses"] == 0
+    got, st = emu.decode_coefs(data, gold["coefs"].shape[0], 64, 1, 1)
+    assert np.array_equal(got, gold["coefs"]) and st["spec_guesses"] > 100 and st["spec_mended_max"] > 1
+
+
+def test_speculative_map_primitives():
+    """mj_spec_core.h through the emulation's export: indices of the candidates, who goes on,
+    who ends, and the composition of maps."""
+    lib = C.CDLL(binding.EMU_PATH)
+    lib.mj_emu_spec_selftest.restype = C.c_int
+    assert lib.mj_emu_spec_selftest() == 0
+
+
 def test_emulation_exercises_the_cross_sequence_path():
     emu = J.Emu()
     data, gold = load_fixture("C1_c420_q85_512x512")

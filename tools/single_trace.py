@@ -49,6 +49,8 @@ if __name__ == "__main__":
     import jpeg_decoder_amd as J
     wl, reps = sys.argv[1], int(sys.argv[2])
     n = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+    if os.environ.get("MJ_SYNC_POLICY"):          # "mode,sub_bits,lane_subs,extra" (mj_set_sync_policy)
+        J.binding.set_sync_policy(*[int(x) for x in os.environ["MJ_SYNC_POLICY"].split(",")])
     ctx = J.Context(0)
     files = [J.synth.config_jpeg(wl, 1 + i) for i in range(n)]
     for _ in range(reps):
