@@ -610,6 +610,7 @@ def main():
     for bt in batches:
         for k, v in bt.entropy_stats().items():
             stats[k] = max(stats.get(k, 0), v) if k.endswith("_max") else stats.get(k, 0) + v
+    speculative = stats.get("workgroups", 0) == 0 and stats.get("subsequences", 0) > 0     # no workgroup ran the rounds
     mismatched = 0
     parity = None
     if digests is not None and n_streams == 1:
@@ -811,13 +812,16 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(k_avg_ms, 4),
                          "measured_in": "resident region"},
-            "entropy": {"kernel": "mj_k_entropy_sync (+fix/write)", "avg_launch_ms": round(e_avg_ms, 4),
-                        "decoded_Gbit_per_s": round(8.0 * comp_bytes_rank / n_streams / (e_avg_ms * 1e-3) / 1e9, 2) if e_avg_ms else None,
-                        "Gbit_per_s_per_CU": round(8.0 * comp_bytes_rank / n_streams / (e_avg_ms * 1e-3) / 1e9 / N_CUS, 4) if e_avg_ms else None,
-                        "sync_rounds_avg": round(stats["rounds_sum"] / max(stats["workgroups"], 1), 2),
-                        "sync_rounds_max": stats["rounds_max"], "sequences": stats["sequences"],
-                        "subsequences": stats["subsequences"],
-                        "redecoded_fraction": round(stats["round_tasks"] / max(stats["subsequences"], 1), 3)},
+            "entropy": dict({"kernel": ("mj_k_spec_* (+fix/write)" if speculative else "mj_k_entropy_sync (+fix/write)"),
+                             "avg_launch_ms": round(e_avg_ms, 4),
+                             "decoded_Gbit_per_s": round(8.0 * comp_bytes_rank / n_streams / (e_avg_ms * 1e-3) / 1e9, 2) if e_avg_ms else None,
+                             "Gbit_per_s_per_CU": round(8.0 * comp_bytes_rank / n_streams / (e_avg_ms * 1e-3) / 1e9 / N_CUS, 4) if e_avg_ms else None,
+                             "synchronisation": "speculative" if speculative else "rounds",
+                             "sequences": stats["sequences"], "subsequences": stats["subsequences"]},
+                            **({"guessed_hops": stats["rounds_sum"], "subsequences_decoded_again": stats["round_tasks"]} if speculative else
+                               {"sync_rounds_avg": round(stats["rounds_sum"] / max(stats["workgroups"], 1), 2),
+                                "sync_rounds_max": stats["rounds_max"],
+                                "redecoded_fraction": round(stats["round_tasks"] / max(stats["subsequences"], 1), 3)})),
             "end_to_end_hbm": {"algorithmic_bytes_per_px": round(e2e_bytes_px, 3),
                                "frac_of_peak": round(e2e_bytes_px * resident_value * 1e6 / world / (HBM_PEAK_GBS * 1e9), 4)},
             "kernels": kernels,

@@ -78,7 +78,7 @@ constexpr size_t kStaticMetaBytes = 4u << 20;   /* page-locked mirror of the met
 
 /* How batches choose between the rounds and the speculative synchronisation (mj_set_sync_policy). */
 #ifndef MJ_SPEC_MAX_WORK_BITS_PER_CU
-#define MJ_SPEC_MAX_WORK_BITS_PER_CU 2050000u   /* 0.52 Gbit of counting decode on 256 CUs: about a fifth of a millisecond */
+#define MJ_SPEC_MAX_WORK_BITS_PER_CU 4000000u   /* 1.0 Gbit of counting decode on 256 CUs, 0.3 ms: where the rounds take as long (128 files of 512 x 512, or one of 7680 x 4320) */
 #endif
 #ifndef MJ_SPEC_LONG_INTERVAL_BITS
 #define MJ_SPEC_LONG_INTERVAL_BITS 262144u
@@ -106,7 +106,7 @@ struct Offsets {
     size_t dyn, tile_cnt, tile_base, ivl_start, ivl_seq, seq_ivl, seq_sub, seq_entry, seq_seen, seq_flag, multi, multi_count,
         grp_list, pair_list, stats, state_bytes;
     /* work */
-    size_t raw, cmp, rec, spec_rec, spec_map, spec_tot, spec_brk, work_bytes;
+    size_t raw, cmp, rec, spec_rec, spec_map, spec_lane, spec_tot, spec_brk, spec_carry, work_bytes;
     /* out */
     size_t coefs, rgb, planes, out_bytes;
 };
@@ -680,7 +680,9 @@ int layout(mj_batch *b, MjPrep &pp, uint32_t flags, bool may_span, bool may_spec
             const uint32_t x = mj_spec_fit_x(g, spec_bpm, g_sync.extra ? g_sync.extra : spec_default_extra(g));
             if (x == 0) continue;
             const uint64_t work = bits * spec_bpm * (g + x) / g;
-            if (g_sync.mode == 2 || (chains && work <= limit)) {
+            /* lanes of one subsequence only while their work is a third of the limit: past that the
+             * half again that lanes of two save is worth more than the guesses they avoid */
+            if (g_sync.mode == 2 || (chains && work <= (g == 1 ? limit / 3 : limit))) {
                 spec_x = x;
                 spec_g = g;
             }
@@ -861,6 +863,8 @@ int layout(mj_batch *b, MjPrep &pp, uint32_t flags, bool may_span, bool may_spec
 #endif
     d.spec = spec_x;
     d.spec_bpm = spec_bpm;
+    d.spec_long = 0;
+    for (int i = 0; i < n && spec_x; i++) d.spec_long |= (b->img[i].seq_cap > 64u) ? 1u : 0u;      /* SPEC_FOLD_SELF of the kernels */
     d.spec_stride = spec_x ? spec_bpm * mj_spec_len(spec_g, spec_x) : 0;
     d.max_ntab = 1;
     d.max_nac = 1;
@@ -903,8 +907,10 @@ int layout(mj_batch *b, MjPrep &pp, uint32_t flags, bool may_span, bool may_spec
     o.rec = w.take(n_rec * sizeof(MjSubRec));
     o.spec_rec = w.take(spec_x ? n_rec / spec_g * d.spec_stride * sizeof(MjSubRec) : 0);
     o.spec_map = w.take(spec_x ? n_rec * MJ_SPEC_MAXC : 0);
+    o.spec_lane = w.take(spec_x ? n_rec / spec_g * MJ_SPEC_MAXC : 0);
     o.spec_tot = w.take(spec_x ? n_seq * MJ_SPEC_MAXC : 0);
     o.spec_brk = w.take(spec_x ? n_seq * 4 : 0);
+    o.spec_carry = w.take(spec_x ? n_seq : 0);
     o.work_bytes = w.off;
     o.coefs = out.take(b->coef_bytes);
     o.rgb = out.take(rgb_total);
@@ -945,8 +951,10 @@ void bind(mj_batch *b, uint8_t *meta, uint8_t *state, uint8_t *work, uint8_t *co
     d.rec = reinterpret_cast<MjSubRec *>(work + o.rec);
     d.spec_rec = reinterpret_cast<MjSubRec *>(work + o.spec_rec);
     d.spec_map = work + o.spec_map;
+    d.spec_lane = work + o.spec_lane;
     d.spec_tot = work + o.spec_tot;
     d.spec_brk = reinterpret_cast<uint32_t *>(work + o.spec_brk);
+    d.spec_carry = work + o.spec_carry;
     d.coefs = reinterpret_cast<int16_t *>(coefs);
     d.rgb = rgb;
     d.planes = planes;

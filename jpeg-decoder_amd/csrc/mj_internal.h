@@ -71,9 +71,12 @@ struct MjDeviceBatch {
     uint32_t spec_stride;    /* records per lane slot in spec_rec: most block slots per MCU in the batch x (lane_subs + X) */
     uint32_t spec_bpm;       /* most block slots per MCU in the batch */
     MjSubRec *spec_rec;      /* per lane slot (rec_off / lane_subs + 64 x sequence + lane), variant and subsequence of the trajectory */
-    uint8_t *spec_map;       /* per record slot: MJ_SPEC_MAXC bytes, candidate at the sequence's first position -> candidate here */
+    uint8_t *spec_map;       /* per record slot: MJ_SPEC_MAXC bytes, candidate at the first position of the slot's lane -> candidate here */
+    uint8_t *spec_lane;      /* per lane slot: MJ_SPEC_MAXC bytes, candidate at the sequence's first position -> candidate at the lane's first */
     uint8_t *spec_tot;       /* per sequence slot: MJ_SPEC_MAXC bytes, what the whole sequence does to a candidate */
-    uint32_t *spec_brk;      /* per sequence slot: hops of the true chain in it that were guesses */
+    uint32_t *spec_brk;      /* per sequence slot: hops of the true chain in it that were guesses; bit 31: the boundary before it is to be decoded across again */
+    uint8_t *spec_carry;     /* per sequence slot, intervals of many sequences only: the candidate the true chain enters the sequence at */
+    uint32_t spec_long;      /* some interval may have so many sequences that mj_k_spec_carry is launched */
     const MjIdctImg *idct_img; /* [n_img] what the IDCT + colour kernel reads per image */
     const MjCombine *comb;   /* [n_comb] frames coded in one scan per component */
     uint32_t n_comb, comb_max_x, comb_max_y;

@@ -665,11 +665,17 @@ __global__ __launch_bounds__(MJ_WG_SEQS * 64) void mj_k_entropy_fix_first(MjDevi
     if (lane == 0) b.seq_flag[im.seq_off + sq] = 0;
     if (first != 0) {
         const MjState e = rec[-1].exit;
-        if (lane == 0) b.seq_seen[im.seq_off + sq] = e;
         uint32_t p = uni(e.p), kc = uni(e.kc);
-        /* records that come from the speculative synchronisation without a single guess in the
-         * image are one verified chain across all its sequences: nothing to decode again */
-        const uint32_t n_redo = (b.spec && b.dyn[ii].spec_guessed == 0) ? 0u : n;
+        /* records that come from the speculative synchronisation are one verified chain across
+         * the sequences, except where the hop over the boundary was a guess or the mending
+         * replaced the record before it (bit 31 of the sequence's counter): only those
+         * boundaries are decoded across again */
+#if defined(MJ_SPEC_ALWAYS_REDO)
+        const uint32_t n_redo = n;
+#else
+        const uint32_t n_redo = (b.spec && !(b.spec_brk[im.seq_off + sq] & 0x80000000u)) ? 0u : n;
+#endif
+        if (lane == 0 && n_redo) b.seq_seen[im.seq_off + sq] = e;
         for (uint32_t l = 0; l < n_redo; l++) {
             const MjState old = rec[l].exit;
             const LaneRec o = solo_nowrite(cx, p, kc, sub_end(g.b0, g.b1, g.nsub, first + l, S), lane);
@@ -683,7 +689,7 @@ __global__ __launch_bounds__(MJ_WG_SEQS * 64) void mj_k_entropy_fix_first(MjDevi
      * summing them would keep its one workgroup in mj_k_entropy_fix busy for long: that kernel
      * then sums again only the sequences it has to decode once more */
     if (g.nseq > FIX_TOTALS_EARLY) {
-        __threadfence();        /* lane 0's records, before the other lanes read them */
+        if (first != 0) __threadfence_block();        /* lane 0's records, before the other lanes of the wavefront read them */
         sequence_totals(rec, n, lane, &b.seq_entry[im.seq_off + sq]);
     }
 }
@@ -1056,15 +1062,18 @@ __global__ __launch_bounds__(SPEC_TPB) void mj_k_spec_decode(MjDeviceBatch b) {
     }
 }
 
-/* out = second after first; maps are MJ_SPEC_MAXC bytes in LDS, read and written a word at a time */
-__device__ __forceinline__ void spec_compose(const uint8_t *first, const uint8_t *second, uint8_t *out) {
+/* out = second after first; maps are MJ_SPEC_MAXC bytes in LDS, read and written a word at a
+ * time, the first nw words of them (the candidates a batch can have: wave-uniform) */
+__device__ __forceinline__ void spec_compose(const uint8_t *first, const uint8_t *second, uint8_t *out, uint32_t nw) {
     const uint32_t *f = reinterpret_cast<const uint32_t *>(first);
     uint32_t *o = reinterpret_cast<uint32_t *>(out);
 #pragma unroll
     for (int w = 0; w < MJ_SPEC_MAXC / 4; w++) {
-        const uint32_t x = f[w];
-        o[w] = (uint32_t) second[x & MJ_SPEC_IDX] | ((uint32_t) second[(x >> 8) & MJ_SPEC_IDX] << 8) |
-               ((uint32_t) second[(x >> 16) & MJ_SPEC_IDX] << 16) | ((uint32_t) second[(x >> 24) & MJ_SPEC_IDX] << 24);
+        if ((uint32_t) w < nw) {
+            const uint32_t x = f[w];
+            o[w] = (uint32_t) second[x & MJ_SPEC_IDX] | ((uint32_t) second[(x >> 8) & MJ_SPEC_IDX] << 8) |
+                   ((uint32_t) second[(x >> 16) & MJ_SPEC_IDX] << 16) | ((uint32_t) second[(x >> 24) & MJ_SPEC_IDX] << 24);
+        }
     }
 }
 __device__ __forceinline__ void spec_identity(uint8_t *m) {
@@ -1078,7 +1087,19 @@ __device__ __forceinline__ void spec_copy(const uint8_t *src, uint8_t *dst) {   
     d[0] = a[0];
     d[1] = a[1];
 }
+/* words of a map that hold candidates: (lanes alive at a position) x (block slots), in fours */
+__device__ __forceinline__ uint32_t spec_words(const MjDeviceBatch &b, uint32_t G) {
+    return ((mj_spec_back(G, b.spec) + 1u) * b.spec_bpm + 3u) / 4u;
+}
 
+/* Per sequence, by one wavefront.  Lane l has the positions l * G .. l * G + G - 1 of the
+ * sequence.  It builds their maps one after the other in LDS -- the entries the indices decide,
+ * and at the one position of the lane where trajectories end (those of the lane mj_spec_back
+ * lanes before it) the entries of the variants that end, from the recorded states -- and
+ * composes them as it goes: what is stored per position is the map from the candidate at the
+ * lane's first position to the candidate there.  A scan over the lanes' totals then gives
+ * every lane the map from the sequence's first position to its own first position, and the
+ * sequence its total.  (mj_k_spec_resolve applies the two maps one after the other.) */
 __global__ __launch_bounds__(SPEC_TPB) void mj_k_spec_maps(MjDeviceBatch b) {
     /* dynamic LDS: three maps per thread */
     uint32_t ii, seq0, n_seq;
@@ -1090,82 +1111,109 @@ __global__ __launch_bounds__(SPEC_TPB) void mj_k_spec_maps(MjDeviceBatch b) {
     const uint32_t G = im.lane_subs, X = b.spec, LEN = mj_spec_len(G, X), bpm = im.bpm;
     uint8_t *maps = b.spec_map + (uint64_t) s.rec_base * MJ_SPEC_MAXC;
     auto M = [&](uint32_t k, uint32_t l) -> uint8_t * { return s_dyn + (size_t) (k * blockDim.x + (wave << 6) + l) * MJ_SPEC_MAXC; };
-
     const uint32_t lg = 31u - (uint32_t) __clz((int) G);       /* lane_subs is a power of two */
     const uint32_t back = mj_spec_back(G, X);
-    /* the maps of the lane's positions as far as indices decide them (a position has a map when
-     * a subsequence follows it in its interval), put together in LDS */
+    const uint32_t nw = spec_words(b, G);
+
+    /* The position of the lane where trajectories end (LEN - 1, LEN - 1 + G, ... of the
+     * interval), if it has a map at all: the states of the candidates that go on there -- those
+     * of the lanes after the one that ends -- and of the variants that end, all loads at once. */
+    const uint32_t q_end = (LEN - 1u) & (G - 1u);
+    const uint32_t m_end = s.first + lane * G + q_end;
+    const bool ends = lane * G + q_end < s.n && m_end + 1 < s.g.nsub && m_end >= LEN - 1u;
+    const uint32_t r_end = (LEN - 1u - q_end) >> lg;
+    uint32_t hop[(MJ_MAX_BPM + 3) / 4] = {0, 0, 0};       /* the entries of the variants that end, a byte each */
+    if (ends) {
+        const uint32_t l0 = m_end >> lg;
+        uint64_t theirs[MJ_SPEC_MAX_BACK][MJ_MAX_BPM], mine[MJ_MAX_BPM];
+        uint32_t their_next[MJ_SPEC_MAX_BACK][MJ_MAX_BPM];
+#pragma unroll
+        for (uint32_t r2 = 0; r2 < MJ_SPEC_MAX_BACK; r2++) {
+#pragma unroll
+            for (uint32_t v2 = 0; v2 < MJ_MAX_BPM; v2++) {
+                const bool on = r2 < r_end && v2 < bpm && mj_spec_valid(G, X, l0, q_end, r2, v2);
+                their_next[r2][v2] = on ? mj_spec_next(G, X, bpm, q_end, r2, v2) : (uint32_t) MJ_SPEC_END;
+                theirs[r2][v2] = 0;
+                if (on) {
+                    const MjState st = spec_nodes(b, s, l0 - r2, v2, LEN)[mj_spec_age(G, q_end, r2)].exit;
+                    theirs[r2][v2] = mj_spec_state(st.p, st.kc);
+                }
+            }
+        }
+#pragma unroll
+        for (uint32_t v = 0; v < MJ_MAX_BPM; v++) {
+            mine[v] = 0;
+            if (v < bpm && mj_spec_valid(G, X, l0, q_end, r_end, v)) {
+                const MjState st = spec_nodes(b, s, l0 - r_end, v, LEN)[LEN - 1u].exit;
+                mine[v] = mj_spec_state(st.p, st.kc);
+            }
+        }
+        /* nearly always some candidate stands exactly where the one that ends stands: look for
+         * that first (the youngest lane first), and rank the others only for the variants
+         * that found none */
+        uint32_t none = 0;
+#pragma unroll
+        for (uint32_t v = 0; v < MJ_MAX_BPM; v++) {
+            if (v < bpm) {
+                uint32_t found = MJ_SPEC_END;
+#pragma unroll
+                for (uint32_t r2 = 0; r2 < MJ_SPEC_MAX_BACK; r2++) {
+#pragma unroll
+                    for (uint32_t v2 = 0; v2 < MJ_MAX_BPM; v2++) {
+                        const bool hit = theirs[r2][v2] == mine[v] && their_next[r2][v2] != MJ_SPEC_END && found == MJ_SPEC_END;
+                        found = hit ? their_next[r2][v2] : found;
+                    }
+                }
+                none |= (found == MJ_SPEC_END && mj_spec_valid(G, X, l0, q_end, r_end, v)) ? 1u << v : 0u;
+                hop[v / 4] |= (found & 0xFFu) << (8 * (v % 4));
+            }
+        }
+        if (none) {
+#pragma unroll
+            for (uint32_t v = 0; v < MJ_MAX_BPM; v++) {
+                if (none & (1u << v)) {
+                    uint32_t rank = 0;
+                    uint8_t e = mj_spec_guess(G, X, bpm, q_end);
+#pragma unroll
+                    for (uint32_t r2 = 0; r2 < MJ_SPEC_MAX_BACK; r2++) {
+#pragma unroll
+                        for (uint32_t v2 = 0; v2 < MJ_MAX_BPM; v2++) {
+                            if (their_next[r2][v2] != MJ_SPEC_END) mj_spec_better(mine[v], theirs[r2][v2], their_next[r2][v2], &rank, &e);
+                        }
+                    }
+                    hop[v / 4] = (hop[v / 4] & ~(0xFFu << (8 * (v % 4)))) | ((uint32_t) e << (8 * (v % 4)));
+                }
+            }
+        }
+    }
+
+    /* the lane's positions one after the other.  All lanes do the same steps (a position without
+     * a map counts as the identity), so the running map is in the same buffer in every lane: 0
+     * and 2 in turn, 1 holds the map being applied. */
+    uint32_t a = 0;
+    spec_identity(M(a, lane));
     for (uint32_t q = 0; q < G; q++) {
         const uint32_t u = lane * G + q, m = s.first + u;
+        if (u < s.n) spec_copy(M(a, lane), maps + (uint64_t) u * MJ_SPEC_MAXC);      /* candidate at the lane's first position -> candidate here */
+        uint8_t *t = M(1, lane);
         if (u < s.n && m + 1 < s.g.nsub) {
-            const uint32_t l0 = m >> lg, a0 = m & (G - 1u);
-            uint8_t *t = M(1, lane);
+            const uint32_t l0 = m >> lg, a0 = q;
             const uint32_t guess = mj_spec_guess(G, X, bpm, a0) * 0x01010101u;
 #pragma unroll
             for (int w = 0; w < MJ_SPEC_MAXC / 4; w++) reinterpret_cast<uint32_t *>(t)[w] = guess;
             for (uint32_t r = 0; r <= back; r++) {
                 for (uint32_t v = 0; v < bpm; v++) t[r * bpm + v] = mj_spec_entry(G, X, bpm, l0, a0, r, v);
             }
-            spec_copy(t, maps + (uint64_t) u * MJ_SPEC_MAXC);
-        }
-    }
-    __threadfence_block();
-    /* The trajectories that end inside the sequence, one per lane and variant: lane t looks at the
-     * t-th position where one ends (positions LEN - 1, LEN - 1 + G, ... of the interval).  The
-     * candidates that go on there are those of the lanes after the one that ends: their states
-     * first, all loads at once, then every variant that ends against all of them. */
-    {
-        const uint32_t u = ((LEN - 1u) & (G - 1u)) + lane * G, m = s.first + u;
-        if (u < s.n && m + 1 < s.g.nsub && m >= LEN - 1u) {
-            const uint32_t l0 = m >> lg, a0 = m & (G - 1u);
-            const uint32_t r = (LEN - 1u - a0) >> lg;
-            uint64_t theirs[MJ_SPEC_MAX_BACK][MJ_MAX_BPM];
-            uint32_t their_next[MJ_SPEC_MAX_BACK][MJ_MAX_BPM];
+            if (q == q_end && ends) {
 #pragma unroll
-            for (uint32_t r2 = 0; r2 < MJ_SPEC_MAX_BACK; r2++) {
-#pragma unroll
-                for (uint32_t v2 = 0; v2 < MJ_MAX_BPM; v2++) {
-                    const bool on = r2 < r && v2 < bpm && mj_spec_valid(G, X, l0, a0, r2, v2);
-                    their_next[r2][v2] = on ? mj_spec_next(G, X, bpm, a0, r2, v2) : (uint32_t) MJ_SPEC_END;
-                    theirs[r2][v2] = 0;
-                    if (on) {
-                        const MjState st = spec_nodes(b, s, l0 - r2, v2, LEN)[mj_spec_age(G, a0, r2)].exit;
-                        theirs[r2][v2] = mj_spec_state(st.p, st.kc);
-                    }
+                for (uint32_t v = 0; v < MJ_MAX_BPM; v++) {
+                    if (v < bpm && mj_spec_valid(G, X, l0, a0, r_end, v)) t[r_end * bpm + v] = (uint8_t) (hop[v / 4] >> (8 * (v % 4)));
                 }
             }
-            for (uint32_t v = 0; v < bpm; v++) {
-                if (!mj_spec_valid(G, X, l0, a0, r, v)) continue;
-                const MjState st = spec_nodes(b, s, l0 - r, v, LEN)[LEN - 1u].exit;
-                const uint64_t mine = mj_spec_state(st.p, st.kc);
-                uint32_t rank = 0;
-                uint8_t e = mj_spec_guess(G, X, bpm, a0);
-#pragma unroll
-                for (uint32_t r2 = 0; r2 < MJ_SPEC_MAX_BACK; r2++) {
-#pragma unroll
-                    for (uint32_t v2 = 0; v2 < MJ_MAX_BPM; v2++) {
-                        if (their_next[r2][v2] != MJ_SPEC_END) mj_spec_better(mine, theirs[r2][v2], their_next[r2][v2], &rank, &e);
-                    }
-                }
-                maps[(uint64_t) u * MJ_SPEC_MAXC + r * bpm + v] = e;
-            }
-        }
-    }
-    __threadfence_block();
-
-    /* the lane's own positions composed: what its G subsequences do to a candidate.  All lanes
-     * do the same steps (a position without a map counts as the identity), so the running map
-     * is in the same buffer in every lane: 0 and 2 in turn, 1 holds the map being applied. */
-    uint32_t a = 0;
-    spec_identity(M(a, lane));
-    for (uint32_t q = 0; q < G; q++) {
-        const uint32_t u = lane * G + q, m = s.first + u;
-        if (u < s.n && m + 1 < s.g.nsub) {
-            spec_copy(maps + (uint64_t) u * MJ_SPEC_MAXC, M(1, lane));
         } else {
-            spec_identity(M(1, lane));
+            spec_identity(t);
         }
-        spec_compose(M(a, lane), M(1, lane), M(2 - a, lane));
+        spec_compose(M(a, lane), t, M(2 - a, lane), nw);
         a = 2 - a;
     }
     /* inclusive scan over the lanes: after the step with distance d lane l holds what the lanes
@@ -1173,7 +1221,7 @@ __global__ __launch_bounds__(SPEC_TPB) void mj_k_spec_maps(MjDeviceBatch b) {
     for (uint32_t d = 1; d < 64; d <<= 1) {
         wave_lds_sync();
         if (lane >= d) {
-            spec_compose(M(a, lane - d), M(a, lane), M(2 - a, lane));
+            spec_compose(M(a, lane - d), M(a, lane), M(2 - a, lane), nw);
         } else {
             spec_copy(M(a, lane), M(2 - a, lane));
         }
@@ -1182,29 +1230,80 @@ __global__ __launch_bounds__(SPEC_TPB) void mj_k_spec_maps(MjDeviceBatch b) {
     wave_lds_sync();
     /* what the whole sequence does (the lanes past its end count as the identity) */
     if (lane == 63) spec_copy(M(a, 63), b.spec_tot + (uint64_t) s.seq_slot * MJ_SPEC_MAXC);
-    /* exclusive: what the lanes before this one do */
-    if (lane) {
-        spec_copy(M(a, lane - 1), M(1, lane));
-    } else {
-        spec_identity(M(1, lane));
-    }
-    wave_lds_sync();
-    /* the prefix map of every position -- candidate at the sequence's first position -> candidate
-     * here -- in place of its own map */
-    uint32_t run = 1, base = a, out = 2 - a;
-    for (uint32_t q = 0; q < G; q++) {
-        const uint32_t u = lane * G + q, m = s.first + u;
-        if (u >= s.n) break;
-        if (m + 1 < s.g.nsub) {
-            spec_copy(maps + (uint64_t) u * MJ_SPEC_MAXC, M(base, lane));
+    /* exclusive: what the lanes before this one do -- the candidate at the sequence's first
+     * position -> the candidate at the lane's first position */
+    if (lane * G < s.n) {
+        uint8_t *dst = b.spec_lane + (uint64_t) (s.rec_base / G + lane) * MJ_SPEC_MAXC;
+        if (lane) {
+            spec_copy(M(a, lane - 1), dst);
         } else {
-            spec_identity(M(base, lane));
+            spec_identity(M(1, lane));
+            spec_copy(M(1, lane), dst);
         }
-        spec_compose(M(run, lane), M(base, lane), M(out, lane));
-        spec_copy(M(run, lane), maps + (uint64_t) u * MJ_SPEC_MAXC);
-        const uint32_t t = run;
-        run = out;
-        out = t;
+    }
+}
+
+/* Intervals of more than SPEC_FOLD_SELF sequences: the candidate the true decode is at where it
+ * enters each of their sequences, by one workgroup per interval -- an inclusive scan over the
+ * sequences' total maps, 1024 at a time, and candidate 0 taken through it.  (A wavefront of
+ * mj_k_spec_resolve folds the maps before its sequence by itself when they are few.) */
+constexpr uint32_t SPEC_FOLD_SELF = 64;
+constexpr int SPEC_CARRY_TPB = 512;
+constexpr uint32_t SPEC_CARRY_EACH = 4;       /* sequences a thread composes by itself before the scan over the threads */
+
+__global__ __launch_bounds__(SPEC_CARRY_TPB) void mj_k_spec_carry(MjDeviceBatch b) {
+    /* dynamic LDS: three maps per thread */
+    auto M = [&](uint32_t k, uint32_t t) -> uint8_t * { return s_dyn + (size_t) (k * SPEC_CARRY_TPB + t) * MJ_SPEC_MAXC; };
+    const uint32_t n_multi = min(*b.multi_count, b.n_multi_cap);
+    const uint32_t t = threadIdx.x;
+    for (uint32_t entry = blockIdx.x; entry < n_multi; entry += gridDim.x) {
+        const uint2 mi = b.multi[entry];
+        const MjImageDev &im = b.img[mi.x];
+        const uint32_t SQ = MJ_SEQ_LANES * im.lane_subs;
+        const Geo g = interval_geo(b.ivl_start + im.ivl_off, mi.y, im.sub_bits, SQ);
+        if (g.nseq <= SPEC_FOLD_SELF) continue;
+        const uint32_t nw = spec_words(b, im.lane_subs);
+        const uint32_t seq_first = im.seq_off + b.ivl_seq[im.ivl_off + mi.y];
+        const uint8_t *tot = b.spec_tot + (uint64_t) seq_first * MJ_SPEC_MAXC;
+        uint32_t c = 0;                                   /* the candidate where sequence q0 is entered */
+        for (uint32_t q0 = 0; q0 < g.nseq; q0 += SPEC_CARRY_TPB * SPEC_CARRY_EACH) {
+            __syncthreads();
+            /* what the thread's own sequences do, composed in order (the last sequence of the
+             * interval leads nowhere; a thread without sequences holds the identity, and so does
+             * every thread after it) */
+            const uint32_t mine0 = q0 + t * SPEC_CARRY_EACH;
+            uint32_t a = 0;
+            spec_identity(M(a, t));
+            for (uint32_t j = 0; j < SPEC_CARRY_EACH; j++) {
+                if (mine0 + j + 1 < g.nseq) {
+                    spec_copy(tot + (uint64_t) (mine0 + j) * MJ_SPEC_MAXC, M(1, t));
+                    spec_compose(M(a, t), M(1, t), M(2 - a, t), nw);
+                    a = 2 - a;
+                }
+            }
+            /* every thread's running map in buffer 0, then the inclusive scan over the threads between 0 and 2 */
+            if (a != 0) spec_copy(M(2, t), M(0, t));
+            a = 0;
+            for (uint32_t d = 1; d < SPEC_CARRY_TPB; d <<= 1) {
+                __syncthreads();
+                if (t >= d) {
+                    spec_compose(M(a, t - d), M(a, t), M(2 - a, t), nw);
+                } else {
+                    spec_copy(M(a, t), M(2 - a, t));
+                }
+                a = 2 - a;
+            }
+            __syncthreads();
+            /* the thread's first sequence is entered where the threads before it take c; then on through its own */
+            uint32_t e = t ? M(a, t - 1)[c & MJ_SPEC_IDX] : c;
+            for (uint32_t j = 0; j < SPEC_CARRY_EACH; j++) {
+                if (mine0 + j < g.nseq) {
+                    b.spec_carry[seq_first + mine0 + j] = (uint8_t) e;
+                    if (mine0 + j + 1 < g.nseq) e = tot[(uint64_t) (mine0 + j) * MJ_SPEC_MAXC + (e & MJ_SPEC_IDX)];
+                }
+            }
+            c = M(a, SPEC_CARRY_TPB - 1)[c & MJ_SPEC_IDX];
+        }
     }
 }
 
@@ -1219,44 +1318,66 @@ __global__ __launch_bounds__(SPEC_TPB) void mj_k_spec_resolve(MjDeviceBatch b) {
     const uint32_t G = im.lane_subs, X = b.spec, LEN = mj_spec_len(G, X), bpm = im.bpm, SQ = MJ_SEQ_LANES * G;
     (void) X;
     const uint32_t lg = 31u - (uint32_t) __clz((int) G);       /* lane_subs is a power of two */
+    const uint32_t nw = spec_words(b, G);
     /* The candidate the true decode is at where it enters the sequence: candidate 0 at the
      * interval's first position, taken through the total maps of the sequences before this one,
      * 64 of them at a time (a tree of compositions inside the wavefront). */
     uint32_t c = 0;
-    const uint32_t before = s.first / SQ;
+    uint32_t before = s.first / SQ;
+#if defined(MJ_SPEC_NO_CARRY)
+    if (false) {
+#else
+    if (s.g.nseq > SPEC_FOLD_SELF) {              /* mj_k_spec_carry has been here */
+#endif
+        c = b.spec_carry[s.seq_slot];
+        before = 0;
+    }
     const uint8_t *tot = b.spec_tot + (uint64_t) (s.seq_slot - before) * MJ_SPEC_MAXC;
     uint8_t *mine = s_fold[threadIdx.x];
-    for (uint32_t q0 = 0; q0 < before; q0 += 64) {
+    /* 64 maps at a time, the first time fewer: those sit in the last lanes, behind identities (an
+     * identity composed after a map would drop the map's "guess" bit; composed before it, it
+     * changes nothing) */
+    const uint32_t lead = (64u - (before & 63u)) & 63u;
+    for (uint32_t q0 = 0; q0 < before + lead; q0 += 64) {
         wave_lds_sync();
-        if (q0 + lane < before) {
-            spec_copy(tot + (uint64_t) (q0 + lane) * MJ_SPEC_MAXC, mine);
+        if (q0 + lane >= lead) {
+            spec_copy(tot + (uint64_t) (q0 + lane - lead) * MJ_SPEC_MAXC, mine);
         } else {
             spec_identity(mine);
         }
         for (uint32_t d = 1; d < 64; d <<= 1) {
             wave_lds_sync();
-            if ((lane & (2 * d - 1)) == 0) spec_compose(mine, s_fold[threadIdx.x + d], mine);
+            if ((lane & (2 * d - 1)) == 0) spec_compose(mine, s_fold[threadIdx.x + d], mine, nw);
         }
         wave_lds_sync();
         c = s_fold[wave << 6][c & MJ_SPEC_IDX];
     }
-    /* the true candidate at each of the lane's positions, and its record */
+    /* the true candidate at each of the lane's positions -- through the map of the lanes before
+     * this one, then through the map of the lane's positions before this one -- and its record
+     * (the "guess" bit is that of the last hop: of the second map where it is not the identity) */
     const uint8_t *maps = b.spec_map + (uint64_t) s.rec_base * MJ_SPEC_MAXC;
     uint32_t guessed = 0;
+    uint32_t at_lane = c;
+    if (lane && lane * G < s.n) at_lane = b.spec_lane[(uint64_t) (s.rec_base / G + lane) * MJ_SPEC_MAXC + (c & MJ_SPEC_IDX)];
     for (uint32_t q = 0; q < G; q++) {
         const uint32_t u = lane * G + q, m = s.first + u;
         if (u >= s.n) break;
-        const uint32_t e = u ? maps[(uint64_t) u * MJ_SPEC_MAXC + (c & MJ_SPEC_IDX)] : c;
+        const uint32_t e = q ? maps[(uint64_t) u * MJ_SPEC_MAXC + (at_lane & MJ_SPEC_IDX)] : at_lane;
         const uint32_t idx = e & MJ_SPEC_IDX, r = idx / bpm, v = idx % bpm;
         MjSubRec rec = spec_nodes(b, s, (m >> lg) - r, v, LEN)[mj_spec_age(G, m & (G - 1u), r)];
         rec.pad_ = (e & MJ_SPEC_UNVERIFIED) ? 1u : 0u;
         guessed += rec.pad_;
         b.rec[s.rec_base + u] = rec;
+        /* the state the next sequence of the interval is entered with, as its records assume it
+         * (the cross-sequence kernels decode across the boundary again when it is no longer that) */
+        if (u + 1 == s.n && m + 1 < s.g.nsub) b.seq_seen[s.seq_slot + 1] = rec.exit;
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) guessed += __shfl_xor(guessed, d, 64);
     if (lane == 0) {
-        b.spec_brk[s.seq_slot] = guessed;
+        /* bit 31: the boundary before this sequence has to be decoded across again
+         * (mj_k_entropy_fix_first): here because the hop over it was a guess */
+        b.spec_brk[s.seq_slot] = guessed | ((s.first != 0 && (c & MJ_SPEC_UNVERIFIED)) ? 0x80000000u : 0u);
         if (guessed) {
             atomicAdd(&b.stats[MJ_ST_ROUNDS], (unsigned long long) guessed);
             atomicAdd(&b.dyn[ii].spec_guessed, guessed);
@@ -1275,14 +1396,14 @@ __global__ __launch_bounds__(SPEC_TPB) void mj_k_spec_mend(MjDeviceBatch b) {
     const MjImageDev &im = b.img[ii];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
     /* lane t of every wavefront looks at sequence t of the block, so all decide alike whether to stay */
-    const bool some = lane < (blockDim.x >> 6) && seq0 + lane < n_seq && b.spec_brk[im.seq_off + seq0 + lane] != 0;
+    const bool some = lane < (blockDim.x >> 6) && seq0 + lane < n_seq && (b.spec_brk[im.seq_off + seq0 + lane] & 0x7FFFFFFFu) != 0;
     if (!__any(some)) return;
     unsigned char *s_pairs = lds_after_dc(b, 0);
     load_tables(b, im, s_pairs, true);
     __syncthreads();
     if (seq0 + wave >= n_seq) return;
     const SpecSeq s = spec_seq(b, im, seq0 + wave);
-    if (b.spec_brk[s.seq_slot] == 0) return;
+    if ((b.spec_brk[s.seq_slot] & 0x7FFFFFFFu) == 0) return;
     const MjScanCtx cx = make_ctx(b, im, s_pairs, true);
     const uint32_t S = im.sub_bits, G = im.lane_subs;
     MjSubRec *rec = b.rec + s.rec_base;
@@ -1314,6 +1435,8 @@ __global__ __launch_bounds__(SPEC_TPB) void mj_k_spec_mend(MjDeviceBatch b) {
             if (uni(old.p) == o.p && uni(old.kc) == o.kc && uni(next_guessed) == 0) break;
         }
         __threadfence_block();                  /* lane 0's records, before the other lanes look at the flags again */
+        /* the last record of the sequence replaced: the sequence after it (same interval) is entered from another state */
+        if (l + 1 >= s.n && s.first + s.n < s.g.nsub && lane == 0) atomicOr(&b.spec_brk[s.seq_slot + 1], 0x80000000u);
         cursor = l + 1;
     }
     if (lane == 0 && decoded) atomicAdd(&b.stats[MJ_ST_TASKS], (unsigned long long) decoded);
@@ -1406,6 +1529,10 @@ hipError_t mj_launch_spec(const MjDeviceBatch &b, hipStream_t s) {
     const size_t lds = table_lds(b, 0) + (size_t) b.max_nac * sizeof(MjHuffRun);
     hipLaunchKernelGGL(mj_k_spec_decode, dim3(b.n_entropy_wg * (MJ_WG_SEQS / wd), b.spec_bpm), dim3(wd * 64), lds, s, b);
     hipLaunchKernelGGL(mj_k_spec_maps, dim3(b.n_entropy_wg * (MJ_WG_SEQS / wo)), dim3(wo * 64), (size_t) 3 * wo * 64 * MJ_SPEC_MAXC, s, b);
+    if (b.spec_long && b.n_multi_cap) {
+        hipLaunchKernelGGL(mj_k_spec_carry, dim3(b.n_multi_cap < cus ? b.n_multi_cap : cus), dim3(SPEC_CARRY_TPB),
+                           (size_t) 3 * SPEC_CARRY_TPB * MJ_SPEC_MAXC, s, b);
+    }
     hipLaunchKernelGGL(mj_k_spec_resolve, dim3(b.n_entropy_wg * (MJ_WG_SEQS / wo)), dim3(wo * 64), (size_t) wo * 64 * MJ_SPEC_MAXC, s, b);
     hipLaunchKernelGGL(mj_k_spec_mend, dim3(b.n_entropy_wg * (MJ_WG_SEQS / wo)), dim3(wo * 64), lds, s, b);
     return hipGetLastError();

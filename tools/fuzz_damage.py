@@ -14,6 +14,8 @@ big = J.synth.encode_jpeg(J.synth.synth_image(1600, 1200, 9), "4:2:0", 90, 0)   
 # frames coded in one scan per component: any of the three scans is damaged
 per_comp = [J.synth.encode_jpeg(J.synth.synth_image(w, h, 11 + w), s_, q, ri, optimise=o, scans_per_component=True)
             for (w, h, s_, q, ri, o) in ((200, 120, "4:2:0", 85, 0, False), (97, 61, "4:2:2", 75, 5, True), (640, 480, "4:4:4", 90, 80, False))]
+if os.environ.get("MJ_SYNC_POLICY"):          # "mode,sub_bits,lane_subs,extra" (mj_set_sync_policy)
+    binding.set_sync_policy(*[int(x) for x in os.environ["MJ_SYNC_POLICY"].split(",")])
 ctx = J.Context(0)
 rng = np.random.default_rng(int(sys.argv[1]))
 def scan_starts(data):

@@ -8,6 +8,8 @@ from jpeg_decoder_amd import binding
 from refbind import Oracle
 import torch
 orc = Oracle()
+if os.environ.get("MJ_SYNC_POLICY"):          # "mode,sub_bits,lane_subs,extra" (mj_set_sync_policy)
+    binding.set_sync_policy(*[int(x) for x in os.environ["MJ_SYNC_POLICY"].split(",")])
 ctx = J.Context(0)
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 samplings = ["4:4:4", "4:2:2", "4:2:0", "4:4:0", "4:1:1"]
