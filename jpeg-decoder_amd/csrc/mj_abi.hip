@@ -863,6 +863,7 @@ int layout(mj_batch *b, MjPrep &pp, uint32_t flags, bool may_span, bool may_spec
 #endif
     d.spec = spec_x;
     d.spec_bpm = spec_bpm;
+    d.spec_g = spec_g;
     d.spec_long = 0;
     for (int i = 0; i < n && spec_x; i++) d.spec_long |= (b->img[i].seq_cap > 64u) ? 1u : 0u;      /* SPEC_FOLD_SELF of the kernels */
     d.spec_stride = spec_x ? spec_bpm * mj_spec_len(spec_g, spec_x) : 0;

@@ -70,6 +70,7 @@ struct MjDeviceBatch {
     uint32_t spec;           /* 0: the rounds of mj_k_entropy_sync; else X, the subsequences a lane decodes past its own */
     uint32_t spec_stride;    /* records per lane slot in spec_rec: most block slots per MCU in the batch x (lane_subs + X) */
     uint32_t spec_bpm;       /* most block slots per MCU in the batch */
+    uint32_t spec_g;         /* the lane_subs every image of the batch has then */
     MjSubRec *spec_rec;      /* per lane slot (rec_off / lane_subs + 64 x sequence + lane), variant and subsequence of the trajectory */
     uint8_t *spec_map;       /* per record slot: MJ_SPEC_MAXC bytes, candidate at the first position of the slot's lane -> candidate here */
     uint8_t *spec_lane;      /* per lane slot: MJ_SPEC_MAXC bytes, candidate at the sequence's first position -> candidate at the lane's first */

@@ -872,11 +872,37 @@ __global__ __launch_bounds__(TPB) void mj_k_entropy_write(MjDeviceBatch b) {
     const uint32_t n = min(g.nsub - first, SQ);
     MjScanCtx cx = make_ctx(b, im, s_next, false);
     cx.natpos = s_natpos;
-    /* the lane's subsequences: u0 .. u0 + cnt - 1 of the sequence */
-    const uint32_t u0 = lane * G;
+    /* The lane's subsequences: u0 .. u0 + cnt - 1 of the sequence.  A sequence is written by one
+     * wavefront, each lane taking lane_subs subsequences, or (gridDim.y > 1: small batches, where
+     * what counts is how long one lane takes) by gridDim.y wavefronts of different blocks, each
+     * taking a run of 64 shorter lanes; the records are per subsequence, so a wavefront finds
+     * the blocks and DC differences that precede its run by summing the records before it. */
+    const uint32_t Gw = G / gridDim.y, ub = blockIdx.y * MJ_SEQ_LANES * Gw;
+    if (ub >= n) return;
+    const uint32_t u0 = ub + lane * Gw;
     const bool valid = u0 < n;
-    const uint32_t cnt = valid ? min(G, n - u0) : 0u;
+    const uint32_t cnt = valid ? min(Gw, n - u0) : 0u;
     const MjSubRec *recs = b.rec + im.rec_off + (uint64_t) seq * SQ;
+    uint32_t pre_nb = 0;
+    int32_t pre0 = 0, pre1 = 0, pre2 = 0, pre3 = 0;
+    if (ub) {
+        for (uint32_t t = lane; t < ub; t += 64) {
+            const MjSubRec r = recs[t];
+            pre_nb += r.nb;
+            pre0 += r.dcsum[0];
+            pre1 += r.dcsum[1];
+            pre2 += r.dcsum[2];
+            pre3 += r.dcsum[3];
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            pre_nb += __shfl_xor(pre_nb, d, 64);
+            pre0 += __shfl_xor(pre0, d, 64);
+            pre1 += __shfl_xor(pre1, d, 64);
+            pre2 += __shfl_xor(pre2, d, 64);
+            pre3 += __shfl_xor(pre3, d, 64);
+        }
+    }
     uint32_t nb = 0, last_p = 0, last_kc = 0;
     int32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0;
     for (uint32_t q = 0; q < cnt; q++) {
@@ -900,6 +926,14 @@ __global__ __launch_bounds__(TPB) void mj_k_entropy_write(MjDeviceBatch b) {
     se.blk = blk_base;
     se.pred[0] = se.pred[1] = se.pred[2] = se.pred[3] = 0;
     if (g.nseq > 1) se = b.seq_entry[im.seq_off + seq];
+    if (ub) {
+        se.entry = recs[ub - 1].exit;
+        se.blk += pre_nb;
+        se.pred[0] += pre0;
+        se.pred[1] += pre1;
+        se.pred[2] += pre2;
+        se.pred[3] += pre3;
+    }
 
     /* entry state: where the lane before stopped */
     uint32_t p = __shfl_up(last_p, 1, 64), kc = __shfl_up(last_kc, 1, 64);
@@ -1388,8 +1422,11 @@ __global__ __launch_bounds__(SPEC_TPB) void mj_k_spec_resolve(MjDeviceBatch b) {
 /* Where the chain guessed: the decoder that stands at the last verified state goes on, replacing
  * the records, until it meets a record it agrees with that is not itself followed by a guess.
  * One wavefront per sequence, its guesses in ascending order, one decoder at a time
- * (solo_nowrite); a decoder stops at the end of its sequence, where the cross-sequence kernels
- * take over. */
+ * (solo_nowrite).  After every subsequence the decoder also looks whether another trajectory
+ * alive there stands where it stands (some variant of a younger lane usually does within a
+ * subsequence or two: that is what the speculation rests on) and then copies that trajectory's
+ * records for as long as it lives instead of decoding them.  A decoder stops at the end of its
+ * sequence, where the cross-sequence kernels take over. */
 __global__ __launch_bounds__(SPEC_TPB) void mj_k_spec_mend(MjDeviceBatch b) {
     uint32_t ii, seq0, n_seq;
     if (!spec_my_seq(b, ii, seq0, n_seq)) return;
@@ -1405,7 +1442,8 @@ __global__ __launch_bounds__(SPEC_TPB) void mj_k_spec_mend(MjDeviceBatch b) {
     const SpecSeq s = spec_seq(b, im, seq0 + wave);
     if ((b.spec_brk[s.seq_slot] & 0x7FFFFFFFu) == 0) return;
     const MjScanCtx cx = make_ctx(b, im, s_pairs, true);
-    const uint32_t S = im.sub_bits, G = im.lane_subs;
+    const uint32_t S = im.sub_bits, G = im.lane_subs, X = b.spec, LEN = mj_spec_len(G, X), bpm = im.bpm;
+    const uint32_t lg = 31u - (uint32_t) __clz((int) G), back = mj_spec_back(G, X);
     MjSubRec *rec = b.rec + s.rec_base;
     uint32_t cursor = 0, decoded = 0;
     for (;;) {
@@ -1423,21 +1461,54 @@ __global__ __launch_bounds__(SPEC_TPB) void mj_k_spec_mend(MjDeviceBatch b) {
             continue;
         }
         const MjState e = rec[(int64_t) u0 - 1].exit;     /* u0 == 0: the last record of the sequence before, same interval */
-        uint32_t p = uni(e.p), kc = uni(e.kc), l = u0;
-        for (; l < s.n; l++) {
+        uint32_t p = uni(e.p), kc = uni(e.kc), l = u0, last = u0;       /* last: the last record replaced */
+        bool done = false;
+        while (l < s.n && !done) {
             const MjState old = rec[l].exit;
             const uint32_t next_guessed = (l + 1 < s.n) ? rec[l + 1].pad_ : 0u;
             const LaneRec o = solo_nowrite(cx, p, kc, sub_end(s.g.b0, s.g.b1, s.g.nsub, s.first + l, S), lane);
             if (lane == 0) store_rec(rec + l, o);
+            last = l;
             decoded++;
             p = o.p;
             kc = o.kc;
             if (uni(old.p) == o.p && uni(old.kc) == o.kc && uni(next_guessed) == 0) break;
+            /* Not the chain's record -- but one of the other trajectories alive here may stand
+             * exactly where the decoder stands (lane i looks at candidate i): its records are then
+             * the true ones for as long as it lives, and are copied instead of decoded. */
+            const uint32_t m = s.first + l, l0 = m >> lg, a0 = m & (G - 1u);
+            const uint32_t r2 = lane / bpm, v2 = lane % bpm;
+            bool hit = false;
+            if (r2 <= back && mj_spec_valid(G, X, l0, a0, r2, v2) && mj_spec_next(G, X, bpm, a0, r2, v2) != MJ_SPEC_END) {
+                const MjState st = spec_nodes(b, s, l0 - r2, v2, LEN)[mj_spec_age(G, a0, r2)].exit;
+                hit = st.p == o.p && st.kc == o.kc;
+            }
+            const unsigned long long hits = __ballot(hit);
+            l++;
+            if (hits) {
+                const uint32_t j = (uint32_t) __ffsll((long long) hits) - 1u;      /* the youngest lane first */
+                const uint32_t rj = j / bpm, vj = j % bpm;
+                const MjSubRec *nodes = spec_nodes(b, s, l0 - rj, vj, LEN);
+                for (uint32_t a = mj_spec_age(G, a0, rj) + 1u; a < LEN && l < s.n; a++, l++) {
+                    const MjState was = rec[l].exit;
+                    const uint32_t after_guessed = (l + 1 < s.n) ? rec[l + 1].pad_ : 0u;
+                    MjSubRec r = nodes[a];
+                    r.pad_ = 0;
+                    if (lane == 0) rec[l] = r;
+                    last = l;
+                    p = uni(r.exit.p);
+                    kc = uni(r.exit.kc);
+                    if (uni(was.p) == p && uni(was.kc) == kc && uni(after_guessed) == 0) {
+                        done = true;
+                        break;
+                    }
+                }
+            }
         }
         __threadfence_block();                  /* lane 0's records, before the other lanes look at the flags again */
         /* the last record of the sequence replaced: the sequence after it (same interval) is entered from another state */
-        if (l + 1 >= s.n && s.first + s.n < s.g.nsub && lane == 0) atomicOr(&b.spec_brk[s.seq_slot + 1], 0x80000000u);
-        cursor = l + 1;
+        if (last + 1 >= s.n && s.first + s.n < s.g.nsub && lane == 0) atomicOr(&b.spec_brk[s.seq_slot + 1], 0x80000000u);
+        cursor = last + 1;
     }
     if (lane == 0 && decoded) atomicAdd(&b.stats[MJ_ST_TASKS], (unsigned long long) decoded);
 }
@@ -1552,7 +1623,14 @@ hipError_t mj_launch_entropy_fix(const MjDeviceBatch &b, hipStream_t s) {
 hipError_t mj_launch_entropy_write(const MjDeviceBatch &b, hipStream_t s) {
     if (b.n_entropy_wg == 0) return hipSuccess;
     const size_t lds = table_lds(b, 0) + (size_t) TPB * BLK_STRIDE + (size_t) TPB * 8 + (size_t) b.max_nac * sizeof(MjHuffPair);
-    hipLaunchKernelGGL(mj_k_entropy_write, dim3(b.n_entropy_wg * (MJ_WG_SEQS / WAVES)), dim3(TPB), lds, s, b);
+    /* a lane per subsequence where the sequences are so few (of those that took the speculative
+     * synchronisation, which all have one lane_subs) that a wavefront has its SIMD nearly to itself:
+     * 64 files of 512 x 512 0.085 -> 0.061 ms; one of 7680 x 4320, which fills the chip, 0.088 -> 0.100 */
+    uint32_t cus = 0;
+    const hipError_t e = mj_device_cus(&cus);
+    if (e != hipSuccess) return e;
+    const uint32_t split = (b.spec && (uint64_t) b.n_entropy_wg * MJ_WG_SEQS <= 12ull * cus) ? b.spec_g : 1u;
+    hipLaunchKernelGGL(mj_k_entropy_write, dim3(b.n_entropy_wg * (MJ_WG_SEQS / WAVES), split), dim3(TPB), lds, s, b);
     return hipGetLastError();
 }
 
