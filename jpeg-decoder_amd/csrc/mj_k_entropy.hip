@@ -1629,7 +1629,7 @@ hipError_t mj_launch_entropy_write(const MjDeviceBatch &b, hipStream_t s) {
     uint32_t cus = 0;
     const hipError_t e = mj_device_cus(&cus);
     if (e != hipSuccess) return e;
-    const uint32_t split = (b.spec && (uint64_t) b.n_entropy_wg * MJ_WG_SEQS <= 12ull * cus) ? b.spec_g : 1u;
+    const uint32_t split = (b.spec && (uint64_t) b.n_entropy_wg * MJ_WG_SEQS <= 7ull * cus) ? b.spec_g : 1u;
     hipLaunchKernelGGL(mj_k_entropy_write, dim3(b.n_entropy_wg * (MJ_WG_SEQS / WAVES), split), dim3(TPB), lds, s, b);
     return hipGetLastError();
 }
