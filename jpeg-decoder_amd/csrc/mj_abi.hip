@@ -106,7 +106,7 @@ struct Offsets {
     size_t dyn, tile_cnt, tile_base, ivl_start, ivl_seq, seq_ivl, seq_sub, seq_entry, seq_seen, seq_flag, multi, multi_count,
         grp_list, pair_list, stats, state_bytes;
     /* work */
-    size_t raw, cmp, rec, spec_rec, spec_map, spec_lane, spec_tot, spec_brk, spec_carry, work_bytes;
+    size_t raw, cmp, rec, spec_rec, spec_state, spec_map, spec_lane, spec_tot, spec_brk, spec_carry, work_bytes;
     /* out */
     size_t coefs, rgb, planes, out_bytes;
 };
@@ -864,6 +864,7 @@ int layout(mj_batch *b, MjPrep &pp, uint32_t flags, bool may_span, bool may_spec
     d.spec = spec_x;
     d.spec_bpm = spec_bpm;
     d.spec_g = spec_g;
+    d.spec_lanes = spec_x ? (uint32_t) (n_rec / spec_g) : 0;
     d.spec_long = 0;
     for (int i = 0; i < n && spec_x; i++) d.spec_long |= (b->img[i].seq_cap > 64u) ? 1u : 0u;      /* SPEC_FOLD_SELF of the kernels */
     d.spec_stride = spec_x ? spec_bpm * mj_spec_len(spec_g, spec_x) : 0;
@@ -907,6 +908,7 @@ int layout(mj_batch *b, MjPrep &pp, uint32_t flags, bool may_span, bool may_spec
     o.cmp = w.take(cmp_total + 64);
     o.rec = w.take(n_rec * sizeof(MjSubRec));
     o.spec_rec = w.take(spec_x ? n_rec / spec_g * d.spec_stride * sizeof(MjSubRec) : 0);
+    o.spec_state = w.take(spec_x ? n_rec / spec_g * d.spec_stride * sizeof(MjState) : 0);
     o.spec_map = w.take(spec_x ? n_rec * MJ_SPEC_MAXC : 0);
     o.spec_lane = w.take(spec_x ? n_rec / spec_g * MJ_SPEC_MAXC : 0);
     o.spec_tot = w.take(spec_x ? n_seq * MJ_SPEC_MAXC : 0);
@@ -951,6 +953,7 @@ void bind(mj_batch *b, uint8_t *meta, uint8_t *state, uint8_t *work, uint8_t *co
     d.cmp = work + o.cmp;
     d.rec = reinterpret_cast<MjSubRec *>(work + o.rec);
     d.spec_rec = reinterpret_cast<MjSubRec *>(work + o.spec_rec);
+    d.spec_state = reinterpret_cast<MjState *>(work + o.spec_state);
     d.spec_map = work + o.spec_map;
     d.spec_lane = work + o.spec_lane;
     d.spec_tot = work + o.spec_tot;

@@ -72,6 +72,8 @@ struct MjDeviceBatch {
     uint32_t spec_bpm;       /* most block slots per MCU in the batch */
     uint32_t spec_g;         /* the lane_subs every image of the batch has then */
     MjSubRec *spec_rec;      /* per lane slot (rec_off / lane_subs + 64 x sequence + lane), variant and subsequence of the trajectory */
+    MjState *spec_state;     /* the exit states of spec_rec once more, [variant][subsequence of the trajectory][lane slot] */
+    uint32_t spec_lanes;     /* lane slots in the batch */
     uint8_t *spec_map;       /* per record slot: MJ_SPEC_MAXC bytes, candidate at the first position of the slot's lane -> candidate here */
     uint8_t *spec_lane;      /* per lane slot: MJ_SPEC_MAXC bytes, candidate at the sequence's first position -> candidate at the lane's first */
     uint8_t *spec_tot;       /* per sequence slot: MJ_SPEC_MAXC bytes, what the whole sequence does to a candidate */

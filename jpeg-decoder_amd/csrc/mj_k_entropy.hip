@@ -1045,6 +1045,14 @@ __device__ __forceinline__ MjSubRec *spec_nodes(const MjDeviceBatch &b, const Sp
     return b.spec_rec + ((uint64_t) (s.lane_base + lane) * b.spec_stride + v * len);
 }
 
+/* The exit states once more, where the map kernel finds those of neighbouring lanes next to each
+ * other (it compares every lane's with those of the lanes after it: out of the 32-byte records,
+ * 960 bytes apart from lane to lane, that is a cache line per lane and load -- 160 MB of lines for
+ * 64 small files; from here a wavefront's load is four lines): [variant][subsequence][lane slot] */
+__device__ __forceinline__ MjState *spec_state_at(const MjDeviceBatch &b, const SpecSeq &s, uint32_t lane, uint32_t v, uint32_t a, uint32_t len) {
+    return b.spec_state + ((uint64_t) (v * len + a) * b.spec_lanes + s.lane_base + lane);
+}
+
 /* LDS written by some lanes of a wavefront and read by others of the same wavefront */
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1092,6 +1100,10 @@ __global__ __launch_bounds__(SPEC_TPB) void mj_k_spec_decode(MjDeviceBatch b) {
         if (j0 + a < s.g.nsub) {
             const LaneRec r = run_nowrite(cx, L, sub_end(s.g.b0, s.g.b1, s.g.nsub, j0 + a, S));
             store_rec(dst + a, r);
+            MjState st;
+            st.p = r.p;
+            st.kc = r.kc;
+            *spec_state_at(b, s, lane + (s.first / G), v, a, LEN) = st;
         }
     }
 }
@@ -1169,7 +1181,7 @@ __global__ __launch_bounds__(SPEC_TPB) void mj_k_spec_maps(MjDeviceBatch b) {
                 their_next[r2][v2] = on ? mj_spec_next(G, X, bpm, q_end, r2, v2) : (uint32_t) MJ_SPEC_END;
                 theirs[r2][v2] = 0;
                 if (on) {
-                    const MjState st = spec_nodes(b, s, l0 - r2, v2, LEN)[mj_spec_age(G, q_end, r2)].exit;
+                    const MjState st = *spec_state_at(b, s, l0 - r2, v2, mj_spec_age(G, q_end, r2), LEN);
                     theirs[r2][v2] = mj_spec_state(st.p, st.kc);
                 }
             }
@@ -1178,7 +1190,7 @@ __global__ __launch_bounds__(SPEC_TPB) void mj_k_spec_maps(MjDeviceBatch b) {
         for (uint32_t v = 0; v < MJ_MAX_BPM; v++) {
             mine[v] = 0;
             if (v < bpm && mj_spec_valid(G, X, l0, q_end, r_end, v)) {
-                const MjState st = spec_nodes(b, s, l0 - r_end, v, LEN)[LEN - 1u].exit;
+                const MjState st = *spec_state_at(b, s, l0 - r_end, v, LEN - 1u, LEN);
                 mine[v] = mj_spec_state(st.p, st.kc);
             }
         }
@@ -1596,7 +1608,10 @@ hipError_t mj_launch_spec(const MjDeviceBatch &b, hipStream_t s) {
     /* few sequences: small blocks, so that they spread over the chip (the decode keeps two
      * wavefronts to a block, which share the tables in LDS) */
     const bool few = (uint64_t) b.n_entropy_wg * MJ_WG_SEQS <= 4ull * cus;
-    const uint32_t wd = few ? 2u : (uint32_t) MJ_WG_SEQS, wo = few ? 1u : (uint32_t) MJ_WG_SEQS;
+    /* the kernels without tables: a wavefront per block while that is a handful per compute unit
+     * (maps, resolve) */
+    const bool few_o = (uint64_t) b.n_entropy_wg * MJ_WG_SEQS <= 16ull * cus;
+    const uint32_t wd = few ? 2u : (uint32_t) MJ_WG_SEQS, wo = few_o ? 1u : (uint32_t) MJ_WG_SEQS;
     const size_t lds = table_lds(b, 0) + (size_t) b.max_nac * sizeof(MjHuffRun);
     hipLaunchKernelGGL(mj_k_spec_decode, dim3(b.n_entropy_wg * (MJ_WG_SEQS / wd), b.spec_bpm), dim3(wd * 64), lds, s, b);
     hipLaunchKernelGGL(mj_k_spec_maps, dim3(b.n_entropy_wg * (MJ_WG_SEQS / wo)), dim3(wo * 64), (size_t) 3 * wo * 64 * MJ_SPEC_MAXC, s, b);
@@ -1605,7 +1620,8 @@ hipError_t mj_launch_spec(const MjDeviceBatch &b, hipStream_t s) {
                            (size_t) 3 * SPEC_CARRY_TPB * MJ_SPEC_MAXC, s, b);
     }
     hipLaunchKernelGGL(mj_k_spec_resolve, dim3(b.n_entropy_wg * (MJ_WG_SEQS / wo)), dim3(wo * 64), (size_t) wo * 64 * MJ_SPEC_MAXC, s, b);
-    hipLaunchKernelGGL(mj_k_spec_mend, dim3(b.n_entropy_wg * (MJ_WG_SEQS / wo)), dim3(wo * 64), lds, s, b);
+    const uint32_t wm = few ? 1u : (uint32_t) MJ_WG_SEQS;         /* it loads the tables: many threads to a block unless the blocks are very few */
+    hipLaunchKernelGGL(mj_k_spec_mend, dim3(b.n_entropy_wg * (MJ_WG_SEQS / wm)), dim3(wm * 64), lds, s, b);
     return hipGetLastError();
 }
 
