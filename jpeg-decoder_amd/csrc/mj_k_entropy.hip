@@ -988,7 +988,12 @@ __global__ __launch_bounds__(TPB) void mj_k_entropy_write(MjDeviceBatch b) {
                         const uint4 v = *src;
                         *src = make_uint4(0, 0, 0, 0);
                         if (dst_blk < store_end) {
-                            *reinterpret_cast<uint4 *>(coef_bytes + (uint64_t) dst_blk * 128 + (lane & 7) * 16) = v;
+                            /* not read again before the next kernel, by which time gigabytes have gone
+                             * through the caches: stored past them, so that the stream bytes the lanes
+                             * come back to stay (4K x 256: 3.45 -> 3.35 ms) */
+                            typedef uint32_t nt4 __attribute__((ext_vector_type(4)));
+                            const nt4 nv = {v.x, v.y, v.z, v.w};
+                            __builtin_nontemporal_store(nv, reinterpret_cast<nt4 *>(coef_bytes + (uint64_t) dst_blk * 128 + (lane & 7) * 16));
                         }
                     }
                 }
