@@ -83,6 +83,12 @@ constexpr size_t kStaticMetaBytes = 4u << 20;   /* page-locked mirror of the met
 #ifndef MJ_SPEC_LONG_INTERVAL_BITS
 #define MJ_SPEC_LONG_INTERVAL_BITS 262144u
 #endif
+#ifndef MJ_SPEC_MAX_BITS_PER_BLOCK
+#define MJ_SPEC_MAX_BITS_PER_BLOCK 160u
+#endif
+#ifndef MJ_SPEC_MAX_BITS_PER_BLOCK_SUBSAMPLED
+#define MJ_SPEC_MAX_BITS_PER_BLOCK_SUBSAMPLED 280u     /* MCUs of four blocks or more */
+#endif
 #ifndef MJ_SPEC_SUB_BITS
 #define MJ_SPEC_SUB_BITS 256u
 #endif
@@ -660,21 +666,32 @@ int layout(mj_batch *b, MjPrep &pp, uint32_t flags, bool may_span, bool may_spec
      * further -- fifteen to twenty-four times the work for 4:2:0 -- and has no chain.  It is
      * taken where that work is what the chip does in a fraction of a millisecond and the chains
      * are long: most of the batch in intervals of 256 kbit or more (files with a restart
-     * interval per MCU row synchronise in a few rounds as they are), lanes of one subsequence if
-     * the work allows and of two otherwise (longer lanes start too seldom: too many guesses). */
+     * interval per MCU row synchronise in a few rounds as they are) and next to none of it in
+     * files of very many bits per block, lanes of one subsequence if the work allows and of
+     * two otherwise (longer lanes start too seldom: too many guesses). */
     uint32_t spec_x = 0, spec_g = 0, spec_s = 0, spec_bpm = 1;
     if (may_spec && !(flags & MJ_ENTROPY_SERIAL) && g_sync.mode != 1) {
-        uint64_t bits = 0, long_bits = 0;
+        uint64_t bits = 0, long_bits = 0, dense_bits = 0;
         for (int i = 0; i < n; i++) {
             const MjImageDev &im = prep[i].im;
             bits += im.raw_len * 8;
-            if (im.raw_len * 8 >= (uint64_t) MJ_SPEC_LONG_INTERVAL_BITS * im.n_ivl) long_bits += im.raw_len * 8;
+            if (im.raw_len * 8 >= (uint64_t) MJ_SPEC_LONG_INTERVAL_BITS * im.n_ivl) {
+                /* blocks of many bits are blocks that fill up without an end-of-block symbol, which
+                 * is where a decoder gets its zigzag index right: there the variants of a lane
+                 * stay out of step whatever their slot, and the chain guesses (files of 190 bits
+                 * per block: at 0.4 % of the lane boundaries, of 280: at 7 %) */
+                const uint64_t blocks = (uint64_t) im.n_mcu * im.bpm;
+                /* (measured on 640 x 480 files: 4:4:4 at 190 bits per block is already slower than by rounds,
+                 * 4:2:0 at 270 and 4:2:2 at 180 still a third faster) */
+                if (im.raw_len * 8 > (uint64_t) (im.bpm <= 3 ? MJ_SPEC_MAX_BITS_PER_BLOCK : MJ_SPEC_MAX_BITS_PER_BLOCK_SUBSAMPLED) * blocks) dense_bits += im.raw_len * 8;
+                else long_bits += im.raw_len * 8;
+            }
             spec_bpm = im.bpm > spec_bpm ? im.bpm : spec_bpm;
         }
         uint32_t cus = 0;
         if (mj_device_cus(&cus) != hipSuccess) return set_err("cannot query the device");
         const uint64_t limit = (uint64_t) MJ_SPEC_MAX_WORK_BITS_PER_CU * cus;
-        const bool chains = spec_bpm >= 2 && 2 * long_bits > bits;
+        const bool chains = spec_bpm >= 2 && 2 * long_bits > bits && 16 * dense_bits <= bits;
         for (uint32_t g = 1; g <= MJ_MAX_LANE_SUBS && !spec_x; g *= 2) {
             if (g_sync.lane_subs ? g != g_sync.lane_subs : (g_sync.mode != 2 && g > 2)) continue;
             const uint32_t x = mj_spec_fit_x(g, spec_bpm, g_sync.extra ? g_sync.extra : spec_default_extra(g));
@@ -696,7 +713,13 @@ int layout(mj_batch *b, MjPrep &pp, uint32_t flags, bool may_span, bool may_spec
         MjImageDev &im = b->img[i];
         im = prep[i].im;
         if (spec_x) {
-            im.sub_bits = spec_s;
+            /* a variant falls into step MCU by MCU: subsequences of at least half an MCU of this
+             * file (a q95 4:2:2 file has MCUs of 1,500 bits; with 256-bit subsequences its lanes
+             * guessed at every fifth boundary) */
+            uint32_t sb = spec_s;
+            const uint64_t mcu_bits = im.n_mcu ? im.raw_len * 8 / im.n_mcu : 0;
+            while (!g_sync.sub_bits && sb < 2048u && (uint64_t) sb * 2u < mcu_bits) sb *= 2u;
+            im.sub_bits = sb;
             im.lane_subs = spec_g;
         }
         if (im.raw_len >= (1ull << 28)) {

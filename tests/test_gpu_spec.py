@@ -110,6 +110,25 @@ def test_config1_and_a_long_scan_speculative_and_by_rounds(ctx, oracle, policy):
         b.close()
 
 
+def test_files_of_many_bits_per_block(ctx, oracle, policy):
+    """4:4:4 at q 98 on a noisy picture, 280 bits per block: many blocks fill up without an
+    end-of-block symbol and the variants of a lane stay out of step, so speculation guesses at
+    several per cent of the lane boundaries.  Forced, it still gives the restatement's bits;
+    left to itself the library takes the rounds for such a file."""
+    d = J.synth.encode_jpeg(J.synth.synth_image(640, 480, seed=7, sigma=12.0), "4:4:4", 98, 0)
+    o = oracle.decode(d)
+    for mode, expect in [(binding.SYNC_AUTO, False), (binding.SYNC_SPECULATIVE, True)]:
+        policy(mode)
+        b = ctx.batch([d], 0)
+        b.decode()
+        st = b.entropy_stats()
+        assert _speculative(b) == expect
+        if expect:
+            assert st["rounds_sum"] > 100          # hops that were guesses
+        _check(b, 0, o.coefs, o.rgb, f"dense file, mode {mode}")
+        b.close()
+
+
 def test_guesses_are_mended(ctx, oracle, policy):
     """Lanes of one 64-bit subsequence and one more: the chain has to guess hundreds of times in
     a 512 x 512 file; the counters say so and the result is the restatement's."""
