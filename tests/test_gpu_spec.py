@@ -129,6 +129,26 @@ def test_files_of_many_bits_per_block(ctx, oracle, policy):
         b.close()
 
 
+@pytest.mark.parametrize("form", [(256, 2, 3), (128, 1, 3), (64, 1, 1)])
+def test_several_intervals_of_many_sequences(ctx, oracle, policy, form):
+    """A 2048 x 2048 file with a restart interval of 8192 MCUs: two intervals of a hundred
+    sequences each with the default lanes (more than a wavefront folds by itself: the carry
+    kernel takes every long interval of the list), beside a small file in the same batch."""
+    big = J.synth.encode_jpeg(J.synth.synth_image(2048, 2048, seed=21, sigma=6.0), "4:2:0", 90, 8192)
+    small = J.synth.config_jpeg("C1", 1001)
+    wants = [oracle.decode(big), oracle.decode(small)]
+    policy(binding.SYNC_SPECULATIVE, *form)
+    b = ctx.batch([big, small], 0)
+    for _ in range(2):
+        b.decode()
+        assert _speculative(b)
+        st = b.entropy_stats()
+        assert st["multi_seq_intervals"] == 3 and st["sequences"] > 2 * 64 + 17
+        for i, o in enumerate(wants):
+            _check(b, i, o.coefs, o.rgb, f"file {i} {form}")
+    b.close()
+
+
 def test_guesses_are_mended(ctx, oracle, policy):
     """Lanes of one 64-bit subsequence and one more: the chain has to guess hundreds of times in
     a 512 x 512 file; the counters say so and the result is the restatement's."""
