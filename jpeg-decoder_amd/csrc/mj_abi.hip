@@ -713,12 +713,15 @@ int layout(mj_batch *b, MjPrep &pp, uint32_t flags, bool may_span, bool may_spec
         MjImageDev &im = b->img[i];
         im = prep[i].im;
         if (spec_x) {
-            /* a variant falls into step MCU by MCU: subsequences of at least half an MCU of this
-             * file (a q95 4:2:2 file has MCUs of 1,500 bits; with 256-bit subsequences its lanes
-             * guessed at every fifth boundary) */
+            /* a variant falls into step block by block, the sooner the more blocks the lane's few
+             * subsequences hold: subsequences of at least two blocks of this file (640 x 480 files
+             * of 120 to 130 bits per block guess at one lane boundary in a thousand with 256-bit
+             * subsequences, files of 190 at one in thirty, and at one in five hundred with 512;
+             * lanes twice as long take twice as long, so no longer than that) */
             uint32_t sb = spec_s;
-            const uint64_t mcu_bits = im.n_mcu ? im.raw_len * 8 / im.n_mcu : 0;
-            while (!g_sync.sub_bits && sb < 2048u && (uint64_t) sb * 2u < mcu_bits) sb *= 2u;
+            const uint64_t blocks = (uint64_t) im.n_mcu * im.bpm;
+            const uint64_t block_bits = blocks ? im.raw_len * 8 / blocks : 0;
+            while (!g_sync.sub_bits && sb < 2048u && (uint64_t) sb < 2u * block_bits) sb *= 2u;
             im.sub_bits = sb;
             im.lane_subs = spec_g;
         }

@@ -47,6 +47,8 @@ if __name__ == "__main__":
     import torch
     torch.cuda.init()
     import jpeg_decoder_amd as J
+    if os.environ.get("MJ_LIB"):                  # another build of the library
+        J.binding.LIB_PATH = os.path.abspath(os.environ["MJ_LIB"])
     wl, reps = sys.argv[1], int(sys.argv[2])
     n = int(sys.argv[3]) if len(sys.argv) > 3 else 1
     if os.environ.get("MJ_SYNC_POLICY"):          # "mode,sub_bits,lane_subs,extra" (mj_set_sync_policy)
