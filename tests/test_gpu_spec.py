@@ -110,6 +110,28 @@ def test_config1_and_a_long_scan_speculative_and_by_rounds(ctx, oracle, policy):
         b.close()
 
 
+def test_subsequence_size_follows_bits_per_block(ctx, oracle, policy):
+    """Left to itself the library cuts a speculating file into subsequences of 256 bits, or of the
+    next power of two that holds two blocks of the file: a 512 x 512 4:2:0 file of some ninety bits
+    per block keeps 256 (a lane twice as long takes twice as long), a 4:2:0 file at q 95 on a
+    noisy picture, near 190 bits per block, gets 512."""
+    policy(binding.SYNC_AUTO)
+    light = J.synth.config_jpeg("C1", 1001)
+    heavy = J.synth.encode_jpeg(J.synth.synth_image(640, 480, seed=7, sigma=12.0), "4:2:0", 95, 0)
+    for d, blocks, want_bits in [(light, 1024 * 6, 256), (heavy, 1200 * 6, 512)]:
+        b = ctx.batch([d], 0)
+        b.decode()
+        assert _speculative(b)
+        info = b.info(0)
+        bits = info.entropy_bytes * 8                     # with the stuffed bytes: a little more than the stream
+        assert (want_bits == 256) == (bits < 128 * blocks), (bits, blocks)
+        subs = b.entropy_stats()["subsequences"]
+        assert bits / want_bits * 0.9 < subs <= bits / want_bits + 1, (subs, bits, want_bits)
+        o = oracle.decode(d)
+        _check(b, 0, o.coefs, o.rgb, f"subsequences of {want_bits} bits")
+        b.close()
+
+
 def test_files_of_many_bits_per_block(ctx, oracle, policy):
     """4:4:4 at q 98 on a noisy picture, 280 bits per block: many blocks fill up without an
     end-of-block symbol and the variants of a lane stay out of step, so speculation guesses at
