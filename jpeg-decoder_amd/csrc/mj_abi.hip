@@ -89,6 +89,12 @@ constexpr size_t kStaticMetaBytes = 4u << 20;   /* page-locked mirror of the met
 #ifndef MJ_SPEC_MAX_BITS_PER_BLOCK_SUBSAMPLED
 #define MJ_SPEC_MAX_BITS_PER_BLOCK_SUBSAMPLED 280u     /* MCUs of four blocks or more */
 #endif
+#ifndef MJ_SPEC_FINE_BITS_PER_CU
+#define MJ_SPEC_FINE_BITS_PER_CU 10000u              /* batches up to this size get subsequences finer than MJ_SPEC_SUB_BITS */
+#endif
+#ifndef MJ_SPEC_SUB_BITS_FINE
+#define MJ_SPEC_SUB_BITS_FINE 160u
+#endif
 #ifndef MJ_SPEC_SUB_BITS
 #define MJ_SPEC_SUB_BITS 256u
 #endif
@@ -670,6 +676,7 @@ int layout(mj_batch *b, MjPrep &pp, uint32_t flags, bool may_span, bool may_spec
      * files of very many bits per block, lanes of one subsequence if the work allows and of
      * two otherwise (longer lanes start too seldom: too many guesses). */
     uint32_t spec_x = 0, spec_g = 0, spec_s = 0, spec_bpm = 1;
+    bool spec_fine = false;
     if (may_spec && !(flags & MJ_ENTROPY_SERIAL) && g_sync.mode != 1) {
         uint64_t bits = 0, long_bits = 0, dense_bits = 0;
         for (int i = 0; i < n; i++) {
@@ -705,6 +712,9 @@ int layout(mj_batch *b, MjPrep &pp, uint32_t flags, bool may_span, bool may_spec
             }
         }
         spec_s = g_sync.sub_bits ? (g_sync.sub_bits + 31u) / 32u * 32u : MJ_SPEC_SUB_BITS;
+        /* a file or two on their own: every wavefront has its SIMD to itself and the decode takes as
+         * long as one lane does, so shorter lanes, as short as the files' blocks allow (below) */
+        spec_fine = bits <= (uint64_t) MJ_SPEC_FINE_BITS_PER_CU * cus;
     }
 
     uint64_t raw_total = 0, cmp_total = 0, coef_blocks = 0, rgb_total = 0, plane_total = 0;
@@ -721,7 +731,16 @@ int layout(mj_batch *b, MjPrep &pp, uint32_t flags, bool may_span, bool may_spec
             uint32_t sb = spec_s;
             const uint64_t blocks = (uint64_t) im.n_mcu * im.bpm;
             const uint64_t block_bits = blocks ? im.raw_len * 8 / blocks : 0;
-            while (!g_sync.sub_bits && sb < 2048u && (uint64_t) sb < 2u * block_bits) sb *= 2u;
+            if (!g_sync.sub_bits) {
+                if (spec_fine && 2u * block_bits <= MJ_SPEC_SUB_BITS) {
+                    /* (a 512 x 512 file alone: 187 us with 256 bits, 171 with 192, 165 with 160 -- and 184
+                     * with 128, where the guesses begin; eight of them: 203, 211, 224) */
+                    sb = (uint32_t) ((2u * block_bits + 31u) / 32u * 32u);
+                    sb = sb < MJ_SPEC_SUB_BITS_FINE ? MJ_SPEC_SUB_BITS_FINE : sb;
+                } else {
+                    while (sb < 2048u && (uint64_t) sb < 2u * block_bits) sb *= 2u;
+                }
+            }
             im.sub_bits = sb;
             im.lane_subs = spec_g;
         }

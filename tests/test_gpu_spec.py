@@ -114,21 +114,35 @@ def test_subsequence_size_follows_bits_per_block(ctx, oracle, policy):
     """Left to itself the library cuts a speculating file into subsequences of 256 bits, or of the
     next power of two that holds two blocks of the file: a 512 x 512 4:2:0 file of some ninety bits
     per block keeps 256 (a lane twice as long takes twice as long), a 4:2:0 file at q 95 on a
-    noisy picture, near 190 bits per block, gets 512."""
+    noisy picture, near 190 bits per block, gets 512.  A file or two on their own get shorter
+    ones still: two blocks rounded up to 32 bits, 160 at least."""
     policy(binding.SYNC_AUTO)
-    light = J.synth.config_jpeg("C1", 1001)
+    light = [J.synth.config_jpeg("C1", 1001 + i) for i in range(8)]
     heavy = J.synth.encode_jpeg(J.synth.synth_image(640, 480, seed=7, sigma=12.0), "4:2:0", 95, 0)
-    for d, blocks, want_bits in [(light, 1024 * 6, 256), (heavy, 1200 * 6, 512)]:
-        b = ctx.batch([d], 0)
+    for files, blocks, rule in [(light, 1024 * 6, "coarse"), (light[:1], 1024 * 6, "fine"), ([heavy], 1200 * 6, "coarse")]:
+        b = ctx.batch(files, 0)
         b.decode()
         assert _speculative(b)
-        info = b.info(0)
-        bits = info.entropy_bytes * 8                     # with the stuffed bytes: a little more than the stream
-        assert (want_bits == 256) == (bits < 128 * blocks), (bits, blocks)
+        want_subs = 0
+        for i in range(len(files)):
+            bits = b.info(i).entropy_bytes * 8            # with the stuffed bytes, which is what the library goes by
+            two_blocks = 2 * (bits // blocks)
+            if rule == "fine" and two_blocks <= 256:
+                want_bits = max(160, (two_blocks + 31) // 32 * 32)
+            else:
+                want_bits = 256
+                while want_bits < two_blocks:
+                    want_bits *= 2
+            if files is light or rule == "fine":
+                assert want_bits == (256 if rule == "coarse" else 192), (bits, want_bits)
+            else:
+                assert want_bits == 512, (bits, want_bits)
+            want_subs += bits / want_bits
         subs = b.entropy_stats()["subsequences"]
-        assert bits / want_bits * 0.9 < subs <= bits / want_bits + 1, (subs, bits, want_bits)
-        o = oracle.decode(d)
-        _check(b, 0, o.coefs, o.rgb, f"subsequences of {want_bits} bits")
+        assert want_subs * 0.97 < subs <= want_subs + len(files), (subs, want_subs, rule)
+        for i, d in enumerate(files[:2]):
+            o = oracle.decode(d)
+            _check(b, i, o.coefs, o.rgb, f"{rule} subsequences, file {i}")
         b.close()
 
 
